@@ -1,0 +1,165 @@
+// Module-compatible adapters (gfx950): the reference's modules exchange fp32 NCHW tensors that
+// hold integer*scale.  These kernels convert between that convention and the integer NHWC
+// tensors of the conv kernels, and implement QuantAct's fixed-point paths directly on fp32
+// data so that a Q_ResNet can also be stepped module by module (e.g. for range calibration).
+//   hawq_f32_nchw_to_q_nhwc     quant_modules.py:489-490, 125-126   (x_int = x / S_a)
+//   hawq_acc_nhwc_to_f32_nchw   quant_modules.py:491-494
+//   hawq_fixedpoint_f32         quant_utils.py:363-456
+//   hawq_fakequant_f32          quant_utils.py:73-97, 237-258, 281-308
+//   hawq_avgpool_f32            quant_modules.py:596-602, quant_utils.py:334-337
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void f32_to_q_kernel(const float *__restrict__ x, void *__restrict__ out, int N,
+                                                       int C, int H, int W, int Cpad, int bits, float scale) {
+    const int groups = Cpad >> 3;  // 8 channels per thread
+    const long long HWl = (long long)H * W;
+    const long long total = (long long)N * HWl * groups;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long pix = i % (N * HWl);  // pixel fastest: coalesced reads of each plane
+        const int g = (int)(i / (N * HWl));
+        const int n = (int)(pix / HWl);
+        const long long hw = pix - n * HWl;
+        int q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = g * 8 + k;
+            float v = 0.f;
+            if (c < C) v = rintf(__fdiv_rn(x[((long long)n * C + c) * HWl + hw], scale));
+            q[k] = (int)v;
+        }
+        const long long elem = pix * Cpad + g * 8;
+        if (bits == 8) {
+            v2i o;
+            o.x = (int)pack4_i8(q[0], q[1], q[2], q[3]);
+            o.y = (int)pack4_i8(q[4], q[5], q[6], q[7]);
+            *reinterpret_cast<v2i *>((int8_t *)out + elem) = o;
+        } else {
+            *reinterpret_cast<uint32_t *>((uint8_t *)out + (elem >> 1)) = pack8_u4(q);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void acc_to_f32_kernel(const int32_t *__restrict__ acc, float *__restrict__ y, int N,
+                                                         int C, int H, int W, int Cpad,
+                                                         const float *__restrict__ fscale) {
+    const long long HWl = (long long)H * W;
+    const long long total = (long long)N * C * HWl;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long hw = i % HWl;
+        const long long r = i / HWl;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        y[i] = __fmul_rn((float)acc[((long long)n * HWl + hw) * Cpad + c], fscale[c]);
+    }
+}
+
+__device__ __forceinline__ int to_int(const float z, const float s_a, const float s_w) {
+    return (int)rintf(__fdiv_rn(__fdiv_rn(z, s_a), s_w));  // torch.round(z / S_a / S_w)
+}
+
+__global__ __launch_bounds__(256) void fixedpoint_kernel(const float *__restrict__ z, float *__restrict__ y, int N,
+                                                         int C, int HW, float s_a, const float *__restrict__ s_w,
+                                                         const int32_t *__restrict__ m, const int32_t *__restrict__ e,
+                                                         int per_ch, const float *__restrict__ ident, float s_ida,
+                                                         const float *__restrict__ s_idw,
+                                                         const int32_t *__restrict__ m_id,
+                                                         const int32_t *__restrict__ e_id, int per_ch_id, float s_out,
+                                                         int do_clamp, int q_lo, int q_hi) {
+    const long long total = (long long)N * C * HW;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)((i / HW) % C);
+        const int k = per_ch == 1 ? 0 : c;
+        int q;
+        if (ident == nullptr) {
+            q = dyadic_rne(to_int(z[i], s_a, s_w[k]), m[k], e[k]);
+        } else {
+            const int k1 = per_ch_id == 1 ? 0 : c;
+            const float idv = ident[i];
+            const int wx = to_int(idv, s_ida, s_idw[k1]);
+            const int wy = to_int(__fsub_rn(z[i], idv), s_a, s_w[k]);  // wy = z - identity in binary32
+            q = dyadic_rne(wx, m_id[k1], e_id[k1]) + dyadic_rne(wy, m[k], e[k]);
+        }
+        if (do_clamp) q = clampi(q, q_lo, q_hi);
+        y[i] = __fmul_rn((float)q, s_out);
+    }
+}
+
+__global__ __launch_bounds__(256) void fakequant_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                        long long n, float inv_scale, float scale, int lo, int hi) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float r = rintf(__fmul_rn(inv_scale, x[i]));
+        r = fminf(fmaxf(r, (float)lo), (float)hi);
+        y[i] = __fmul_rn(r, scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_f32_kernel(const float *__restrict__ x, float *__restrict__ y, int NC,
+                                                          int HW, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NC) return;
+    long long s = 0;
+    for (int k = 0; k < HW; ++k) s += (long long)rintf(__fdiv_rn(x[(long long)i * HW + k], scale));
+    const long long p = (100 * s + HW) / (100ll * HW);
+    y[i] = __fmul_rn((float)p, scale);
+}
+
+inline int grid_for(long long work_items) {
+    long long g = (work_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int hawq_f32_nchw_to_q_nhwc(const float *x, void *out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                       int32_t Cpad, int32_t bits, float scale, void *stream) {
+    HAWQ_REQUIRE(x && out, "hawq_f32_nchw_to_q_nhwc: null pointer");
+    HAWQ_REQUIRE(Cpad >= C && Cpad % 8 == 0 && (bits == 8 || bits == 4), "hawq_f32_nchw_to_q_nhwc: bad Cpad/bits");
+    hipLaunchKernelGGL(f32_to_q_kernel, dim3(grid_for((long long)N * H * W * (Cpad / 8))), dim3(256), 0,
+                       (hipStream_t)stream, x, out, N, C, H, W, Cpad, bits, scale);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_acc_nhwc_to_f32_nchw(const int32_t *acc, float *y, int32_t N, int32_t C, int32_t H, int32_t W,
+                                         int32_t Cpad, const float *fscale, void *stream) {
+    HAWQ_REQUIRE(acc && y && fscale, "hawq_acc_nhwc_to_f32_nchw: null pointer");
+    hipLaunchKernelGGL(acc_to_f32_kernel, dim3(grid_for((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       acc, y, N, C, H, W, Cpad, fscale);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_fixedpoint_f32(const float *z, float *y, int32_t N, int32_t C, int32_t HW, float s_a,
+                                   const float *s_w, const int32_t *m, const int32_t *e, int32_t per_ch,
+                                   const float *ident, float s_ida, const float *s_idw, const int32_t *m_id,
+                                   const int32_t *e_id, int32_t per_ch_id, float s_out, int32_t do_clamp,
+                                   int32_t q_lo, int32_t q_hi, void *stream) {
+    HAWQ_REQUIRE(z && y && s_w && m && e, "hawq_fixedpoint_f32: null pointer");
+    HAWQ_REQUIRE(per_ch == 1 || per_ch == C, "hawq_fixedpoint_f32: per_ch must be 1 or C");
+    HAWQ_REQUIRE(!ident || (s_idw && m_id && e_id && (per_ch_id == 1 || per_ch_id == C)),
+                 "hawq_fixedpoint_f32: identity tables missing");
+    hipLaunchKernelGGL(fixedpoint_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, z,
+                       y, N, C, HW, s_a, s_w, m, e, per_ch, ident, s_ida, s_idw, m_id, e_id, per_ch_id, s_out,
+                       do_clamp, q_lo, q_hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_fakequant_f32(const float *x, float *y, int64_t n, float inv_scale, float scale, int32_t lo,
+                                  int32_t hi, void *stream) {
+    HAWQ_REQUIRE(x && y && n > 0, "hawq_fakequant_f32: bad arguments");
+    hipLaunchKernelGGL(fakequant_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n,
+                       inv_scale, scale, lo, hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_avgpool_f32(const float *x, float *y, int32_t NC, int32_t HW, float scale, void *stream) {
+    HAWQ_REQUIRE(x && y && NC > 0 && HW > 0, "hawq_avgpool_f32: bad arguments");
+    hipLaunchKernelGGL(avgpool_f32_kernel, dim3((NC + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, NC, HW,
+                       scale);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}

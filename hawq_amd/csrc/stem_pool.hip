@@ -1,0 +1,325 @@
+// Stem, pooling and small tail kernels of the integer ResNet pipeline (gfx950).
+//   hawq_quantize_input      quant_modules.py:271-274 / quant_utils.py:73-97, 237-258
+//   hawq_stem_conv7          quant_modules.py:489-494 + q_resnet.py:117-122 (conv, QuantAct16, ReLU)
+//   hawq_maxpool3s2_requant  q_resnet.py:93,119 (+ first unit's QuantAct, q_resnet.py:234/239)
+//   hawq_requant_residual    quant_modules.py:288-293 (S_w == 1)
+//   hawq_avgpool_requant     quant_modules.py:596-600, quant_utils.py:334-337, q_resnet.py:129-131
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ input quantiser
+// One thread per output pixel: reads 3 planes (coalesced along W), writes one dword (c0,c1,c2,0).
+__global__ __launch_bounds__(256) void quantize_input_kernel(const float *__restrict__ x, int8_t *__restrict__ out,
+                                                             int N, int C, int H, int W, int out_h, int out_w,
+                                                             int pad_top, int pad_left, float inv_scale, int lo,
+                                                             int hi) {
+    const long long total = (long long)N * H * W;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w = (int)(i % W);
+        const long long r = i / W;
+        const int hh = (int)(r % H);
+        const int n = (int)(r / H);
+        int q[4] = {0, 0, 0, 0};
+        for (int c = 0; c < C; ++c) {
+            const float v = x[((long long)(n * C + c) * H + hh) * W + w];
+            const float t = __fmul_rn(inv_scale, v);  // `1. / scale * input` : one binary32 rounding
+            float rr = rintf(t);                      // round-half-even == torch.round
+            rr = fminf(fmaxf(rr, (float)lo), (float)hi);
+            q[c] = (int)rr;
+        }
+        reinterpret_cast<uint32_t *>(out)[((long long)n * out_h + hh + pad_top) * out_w + w + pad_left] =
+            pack4_i8(q[0], q[1], q[2], q[3]);
+    }
+}
+
+// ------------------------------------------------------------------ stem 7x7/2 conv
+__device__ __forceinline__ int cperm(int i) { return (((i >> 2) & 1) << 4) + (i & 3) + ((i >> 3) << 2); }
+
+// Each wave keeps the whole 64x(7x32 B) weight matrix in registers (14 x v4i) and walks pixel
+// tiles of 64 pixels; the B operand (7 rows x 32 contiguous bytes of the padded NHWC4 image per
+// output pixel) is loaded straight from global/L1 - every input byte is reused ~12x by
+// neighbouring pixels and rows, all of it cache hits.
+__global__ __launch_bounds__(256) void stem_conv7_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ wgt,
+                                                         const int32_t *__restrict__ bias,
+                                                         const int32_t *__restrict__ m, const int32_t *__restrict__ e,
+                                                         int N, int Hp, int Wp, int Ho, int Wo, int q_lo, int q_hi,
+                                                         uint16_t *__restrict__ out16, int32_t *__restrict__ out_acc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    v4i wf[2][7];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+            wf[c][kh] = *reinterpret_cast<const v4i *>(wgt + ((c * 32 + cperm(l31)) * 7 + kh) * 32 + h * 16);
+    const int M = N * Ho * Wo;
+    const int ntiles = (M + 63) / 64;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        v16i acc[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][p][r] = 0;
+        const int8_t *src[2];
+        int pix[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            pix[p] = tile * 64 + p * 32 + l31;
+            const int mm = pix[p] < M ? pix[p] : M - 1;
+            const int n = mm / (Ho * Wo);
+            const int r = mm - n * (Ho * Wo);
+            const int oy = r / Wo, ox = r - oy * Wo;
+            src[p] = in + (((long long)n * Hp + 2 * oy) * Wp + 2 * ox) * 4 + h * 16;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            v4i af[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int *s = reinterpret_cast<const int *>(src[p] + (long long)kh * Wp * 4);  // 8-B aligned
+                v2i a = *reinterpret_cast<const v2i *>(s), b = *reinterpret_cast<const v2i *>(s + 2);
+                af[p].x = a.x, af[p].y = a.y, af[p].z = b.x, af[p].w = b.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    acc[c][p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[c][kh], af[p], acc[c][p], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = c * 32 + h * 16;
+            int bb[16], mm[16], ee[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v4i t0 = reinterpret_cast<const v4i *>(bias + ch)[i];
+                v4i t1 = reinterpret_cast<const v4i *>(m + ch)[i];
+                v4i t2 = reinterpret_cast<const v4i *>(e + ch)[i];
+                bb[4 * i] = t0.x, bb[4 * i + 1] = t0.y, bb[4 * i + 2] = t0.z, bb[4 * i + 3] = t0.w;
+                mm[4 * i] = t1.x, mm[4 * i + 1] = t1.y, mm[4 * i + 2] = t1.z, mm[4 * i + 3] = t1.w;
+                ee[4 * i] = t2.x, ee[4 * i + 1] = t2.y, ee[4 * i + 2] = t2.z, ee[4 * i + 3] = t2.w;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (pix[p] >= M) continue;
+                const size_t elem = (size_t)pix[p] * 64 + ch;
+                int v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[c][p][r] + bb[r];
+                if (out_acc) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v4i w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                        reinterpret_cast<v4i *>(out_acc + elem)[i] = w;
+                    }
+                }
+                if (out16) {
+                    int w[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        // QuantAct 16-bit (clamp) then ReLU; both monotone, so they commute with max-pool
+                        const int a = max(clampi(dyadic_rne(v[2 * i], mm[2 * i], ee[2 * i]), q_lo, q_hi), 0);
+                        const int b = max(clampi(dyadic_rne(v[2 * i + 1], mm[2 * i + 1], ee[2 * i + 1]), q_lo, q_hi), 0);
+                        w[i] = min(a, 65535) | (min(b, 65535) << 16);
+                    }
+                    v4i *dst = reinterpret_cast<v4i *>(out16 + elem);
+                    v4i a = {w[0], w[1], w[2], w[3]}, b = {w[4], w[5], w[6], w[7]};
+                    dst[0] = a;
+                    dst[1] = b;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 3x3/2 max-pool (+ QuantAct)
+// thread = 8 channels of one output pixel (16 B of uint16)
+__global__ __launch_bounds__(256) void maxpool_requant_kernel(const uint16_t *__restrict__ in, int N, int H, int W,
+                                                              int C, int Ho, int Wo, uint16_t *__restrict__ res_out,
+                                                              void *__restrict__ out_q, int out_bits, int mq, int eq,
+                                                              int q_lo, int q_hi) {
+    const int cg = C >> 3;
+    const long long total = (long long)N * Ho * Wo * cg;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int g = (int)(i % cg);
+        long long r = i / cg;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        int best[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) best[k] = 0;  // inputs are >= 0 (post-ReLU) and the window is never empty
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const v4i v = *reinterpret_cast<const v4i *>(in + (((long long)n * H + iy) * W + ix) * C + g * 8);
+                const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    best[2 * k] = max(best[2 * k], w[k] & 0xffff);
+                    best[2 * k + 1] = max(best[2 * k + 1], (int)((unsigned)w[k] >> 16));
+                }
+            }
+        }
+        const long long elem = (((long long)n * Ho + oy) * Wo + ox) * C + g * 8;
+        if (res_out) {
+            v4i o;
+            o.x = best[0] | (best[1] << 16);
+            o.y = best[2] | (best[3] << 16);
+            o.z = best[4] | (best[5] << 16);
+            o.w = best[6] | (best[7] << 16);
+            *reinterpret_cast<v4i *>(res_out + elem) = o;
+        }
+        if (out_q) {
+            int q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = clampi(dyadic_rne(best[k], mq, eq), q_lo, q_hi);
+            if (out_bits == 8) {
+                v2i o;
+                o.x = (int)pack4_i8(q[0], q[1], q[2], q[3]);
+                o.y = (int)pack4_i8(q[4], q[5], q[6], q[7]);
+                *reinterpret_cast<v2i *>((int8_t *)out_q + elem) = o;
+            } else {
+                *reinterpret_cast<uint32_t *>((uint8_t *)out_q + (elem >> 1)) = pack8_u4(q);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ stand-alone block-input QuantAct
+__global__ __launch_bounds__(256) void requant_residual_kernel(const void *__restrict__ in, int in_bits, long long n8,
+                                                               void *__restrict__ out_q, int out_bits, int mq, int eq,
+                                                               int q_lo, int q_hi) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        int v[8];
+        if (in_bits == 16) {
+            const v4i t = reinterpret_cast<const v4i *>(in)[i];
+            const int w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[2 * k] = w[k] & 0xffff;
+                v[2 * k + 1] = (int)((unsigned)w[k] >> 16);
+            }
+        } else {
+            const v4i a = reinterpret_cast<const v4i *>(in)[2 * i], b = reinterpret_cast<const v4i *>(in)[2 * i + 1];
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+        }
+        int q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = clampi(dyadic_rne(v[k], mq, eq), q_lo, q_hi);
+        if (out_bits == 8) {
+            v2i o;
+            o.x = (int)pack4_i8(q[0], q[1], q[2], q[3]);
+            o.y = (int)pack4_i8(q[4], q[5], q[6], q[7]);
+            reinterpret_cast<v2i *>(out_q)[i] = o;
+        } else {
+            reinterpret_cast<uint32_t *>(out_q)[i] = pack8_u4(q);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ global average pool + QuantAct
+// thread = one (n, c): strided over HW (tiny tensor: N*49*C elements)
+__global__ __launch_bounds__(256) void avgpool_requant_kernel(const void *__restrict__ in, int in_bits, int N, int HW,
+                                                              int C, int8_t *__restrict__ out,
+                                                              int32_t *__restrict__ pooled, int mq, int eq, int q_lo,
+                                                              int q_hi) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    long long s = 0;
+    for (int k = 0; k < HW; ++k) {
+        const size_t idx = ((size_t)n * HW + k) * C + c;
+        s += in_bits == 16 ? (long long)((const uint16_t *)in)[idx] : (long long)((const int32_t *)in)[idx];
+    }
+    // trunc(sum/HW + 0.01) in exact rationals (== floor(sum/HW) for sum >= 0)
+    const long long p = (100 * s + HW) / (100ll * HW);
+    if (pooled) pooled[i] = (int32_t)p;
+    out[i] = (int8_t)clampi(dyadic_rne((int32_t)p, mq, eq), q_lo, q_hi);
+}
+
+inline int grid_for(long long work_items) {
+    long long g = (work_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int hawq_quantize_input(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W,
+                                   int32_t out_h, int32_t out_w, int32_t pad_top, int32_t pad_left, float inv_scale,
+                                   int32_t lo, int32_t hi, void *stream) {
+    HAWQ_REQUIRE(x && out, "hawq_quantize_input: null pointer");
+    HAWQ_REQUIRE(C >= 1 && C <= 4, "hawq_quantize_input: C=%d must be 1..4", C);
+    HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && out_h >= H + pad_top && out_w >= W + pad_left,
+                 "hawq_quantize_input: bad geometry");
+    hipLaunchKernelGGL(quantize_input_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       x, out, N, C, H, W, out_h, out_w, pad_top, pad_left, inv_scale, lo, hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_stem_conv7(const int8_t *in, const int8_t *wgt, const int32_t *bias, const int32_t *m,
+                               const int32_t *e, int32_t N, int32_t Hp, int32_t Wp, int32_t Ho, int32_t Wo,
+                               int32_t q_lo, int32_t q_hi, uint16_t *out16, int32_t *out_acc, void *stream) {
+    HAWQ_REQUIRE(in && wgt && bias, "hawq_stem_conv7: null pointer");
+    HAWQ_REQUIRE(out16 || out_acc, "hawq_stem_conv7: no output requested");
+    HAWQ_REQUIRE(!out16 || (m && e), "hawq_stem_conv7: out16 needs m/e tables");
+    HAWQ_REQUIRE(Hp >= 2 * (Ho - 1) + 7 && Wp >= 2 * (Wo - 1) + 8 && (Wp % 2) == 0,
+                 "hawq_stem_conv7: padded input %dx%d too small for output %dx%d", Hp, Wp, Ho, Wo);
+    const long long M = (long long)N * Ho * Wo;
+    HAWQ_REQUIRE(M > 0 && M < (1ll << 30), "hawq_stem_conv7: bad size");
+    const long long tiles = (M + 63) / 64;
+    long long grid = (tiles + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    if (!m) m = bias, e = bias;  // never dereferenced for out16 == NULL, keeps loads in-bounds
+    hipLaunchKernelGGL(stem_conv7_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, in, wgt, bias, m, e, N,
+                       Hp, Wp, Ho, Wo, q_lo, q_hi, out16, out_acc);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_maxpool3s2_requant(const uint16_t *in, int32_t N, int32_t H, int32_t W, int32_t C,
+                                       uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq, int32_t eq,
+                                       int32_t q_lo, int32_t q_hi, void *stream) {
+    HAWQ_REQUIRE(in && (res_out || out_q), "hawq_maxpool3s2_requant: null pointer");
+    HAWQ_REQUIRE(C > 0 && C % 8 == 0, "hawq_maxpool3s2_requant: C must be a multiple of 8");
+    HAWQ_REQUIRE(!out_q || out_bits == 8 || out_bits == 4, "hawq_maxpool3s2_requant: out_bits 4/8");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_requant_kernel, dim3(grid_for((long long)N * Ho * Wo * (C / 8))), dim3(256), 0,
+                       (hipStream_t)stream, in, N, H, W, C, Ho, Wo, res_out, out_q, out_bits, mq, eq, q_lo, q_hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_requant_residual(const void *in, int32_t in_bits, int64_t n, void *out_q, int32_t out_bits,
+                                     int32_t mq, int32_t eq, int32_t q_lo, int32_t q_hi, void *stream) {
+    HAWQ_REQUIRE(in && out_q, "hawq_requant_residual: null pointer");
+    HAWQ_REQUIRE(n > 0 && n % 8 == 0, "hawq_requant_residual: n must be a positive multiple of 8");
+    HAWQ_REQUIRE((in_bits == 16 || in_bits == 32) && (out_bits == 8 || out_bits == 4),
+                 "hawq_requant_residual: in_bits 16/32, out_bits 4/8");
+    hipLaunchKernelGGL(requant_residual_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, in, in_bits,
+                       (long long)(n / 8), out_q, out_bits, mq, eq, q_lo, q_hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, int32_t HW, int32_t C, int8_t *out,
+                                    int32_t *pooled_out, int32_t mq, int32_t eq, int32_t q_lo, int32_t q_hi,
+                                    void *stream) {
+    HAWQ_REQUIRE(in && out, "hawq_avgpool_requant: null pointer");
+    HAWQ_REQUIRE(in_bits == 16 || in_bits == 32, "hawq_avgpool_requant: in_bits 16/32");
+    HAWQ_REQUIRE(N > 0 && HW > 0 && C > 0, "hawq_avgpool_requant: bad geometry");
+    hipLaunchKernelGGL(avgpool_requant_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, in,
+                       in_bits, N, HW, C, out, pooled_out, mq, eq, q_lo, q_hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,377 @@
+"""Fused integer executor for a frozen Q_ResNet on one MI355X.
+
+Walks the frozen network once on the host (the reference redoes all of this on every forward:
+quant_modules.py:441-484, quant_utils.py:188-213), producing
+  * packed int8 / hawq4 weights, int32 biases, per-channel dyadic (m, e) tables on the device,
+  * a launch list of C-ABI calls (include/hawq_mi355.h) in which every tensor between kernels
+    is an integer NHWC tensor at its schedule bit-width:
+
+      quantize_input -> stem_conv7(+QuantAct16+ReLU) -> maxpool(+unit1 QuantAct)
+      per unit:  conv1(+ReLU+QuantAct) -> [conv2(+ReLU+QuantAct)] ->
+                 conv_last(+identity conv in the same launch | +16-bit residual read)
+                          (+residual add, ReLU, next unit's QuantAct, 16-bit residual out)
+      avgpool(+QuantAct8) -> FC(+per-class dequant) -> fp32 logits
+
+  * optionally a hipGraph of the whole list, replayed per batch.
+
+Integer semantics follow SURVEY.md App. A; the graph is q_resnet.py:53-74 / 114-135 / 231-316.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import _lib, packing
+from .quant_utils import requant_table
+
+
+def _i32(arr, dev):
+    return torch.from_numpy(np.ascontiguousarray(arr, np.int32)).to(dev)
+
+
+def _act_range(bits, mode):
+    if mode == 'symmetric':
+        return -(2 ** (bits - 1)), 2 ** (bits - 1) - 1
+    return 0, 2 ** bits - 1
+
+
+class _Conv:
+    """Device-resident parameters of one QuantBnConv2d."""
+
+    def __init__(self, mod, s_a, in_bits, dev, from_buffers):
+        if not from_buffers:
+            mod.prepare(s_a)
+        w_int = mod.weight_integer.detach().cpu().numpy()
+        self.cout, self.cin, self.kh, self.kw = w_int.shape
+        self.stride, self.pad = int(mod.conv.stride[0]), int(mod.conv.padding[0])
+        if mod.conv.groups != 1 or mod.conv.dilation[0] != 1:
+            raise NotImplementedError("grouped/dilated convolutions are outside the ResNet hot path")
+        self.w_bits = 4 if mod.weight_bit <= 4 else 8
+        self.in_bits = in_bits
+        self.s_w = mod.convbn_scaling_factor.detach().float().cpu()
+        self.w_host = w_int
+        b = mod.bias_integer.detach().cpu().numpy().astype(np.float64)
+        self.b_host = np.clip(np.rint(b), -2 ** 31, 2 ** 31 - 1).astype(np.int64)
+        if self.cin % 64 == 0 and self.cout % 64 == 0:
+            self.w = torch.from_numpy(packing.pack_conv_weight(w_int, self.w_bits)).to(dev)
+        self.bias = _i32(self.b_host, dev)
+
+
+class IntegerEngine:
+    """Callable: fp32 NCHW images on the GPU -> fp32 logits, bit-identical to the reference's
+    frozen forward.  ``residual_bits`` 16 stores post-ReLU residuals as uint16 with a sticky
+    overflow flag (``overflowed()``); 32 stores int32.  ``from_buffers`` trusts the modules'
+    integer buffers / scales as loaded from a quantized checkpoint (quant_train.py:665-670)
+    instead of re-deriving them from the float parameters."""
+
+    def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
+                 keep_accumulators: bool = False):
+        if not model.is_frozen():
+            raise RuntimeError("IntegerEngine needs a frozen model (freeze_model) - ranges must be fixed")
+        _lib.load()
+        self.model = model
+        self.dev = next(model.parameters()).device
+        if self.dev.type != 'cuda':
+            raise RuntimeError("IntegerEngine: move the model to the MI355X first (no CPU path)")
+        self.res_bits = residual_bits
+        self.from_buffers = from_buffers
+        self.use_graph = use_graph
+        self.keep_acc = keep_accumulators
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._batch = None
+        self._graph = None
+        self._prepare_params()
+
+    # ------------------------------------------------------------------ host-side preparation
+    def _scale(self, act):
+        if self.from_buffers:
+            return act.act_scaling_factor.detach().float().cpu().reshape(-1)[:1]
+        return act.compute_scale().detach().float().cpu().reshape(-1)[:1]
+
+    def _prepare_params(self):
+        m, dev = self.model, self.dev
+        one = torch.ones(1)
+        P = self.P = {}
+        qi = m.quant_input
+        if qi.activation_bit != 8 or qi.quant_mode != 'symmetric':
+            raise NotImplementedError("quant_input must be 8-bit symmetric (every shipped schedule)")
+        s_in = self._scale(qi)
+        P['s_in'] = s_in
+        P['inv_s_in'] = float((1. / s_in).item())
+        stem = m.stem
+        if tuple(stem.conv.kernel_size) != (7, 7) or stem.conv.stride[0] != 2 or stem.conv.in_channels > 4:
+            raise NotImplementedError("stem must be the 7x7/2 conv of the ImageNet ResNets")
+        sc = _Conv(stem, s_in, 8, dev, self.from_buffers)
+        sc.w = torch.from_numpy(packing.pack_stem_weight(sc.w_host)).to(dev)
+        a0 = m.quant_act_int32
+        s0 = self._scale(a0)
+        mm, ee = requant_table(s_in, sc.s_w, s0)
+        P['stem'] = dict(conv=sc, m=_i32(mm, dev), e=_i32(ee, dev), rng=_act_range(a0.activation_bit, a0.quant_mode))
+        s_prev = s0
+        units = []
+        for name, u in m.units():
+            d = dict(name=name, resize=bool(u.resize_identity), nb=u.n_body)
+            qa = u.quant_act
+            s_a = self._scale(qa)
+            d['a_bits'] = self._store_bits(qa)
+            d['a_rng'] = _act_range(qa.activation_bit, qa.quant_mode)
+            mq, eq = requant_table(s_prev, one, s_a)
+            d['mq'], d['eq'] = int(mq[0]), int(eq[0])
+            if d['resize']:
+                d['ident'] = _Conv(u.quant_identity_convbn, s_a, d['a_bits'], dev, self.from_buffers)
+            s_x, bits_x = s_a, d['a_bits']
+            d['convs'] = []
+            for i in range(1, u.n_body + 1):
+                c = _Conv(getattr(u, f"quant_convbn{i}"), s_x, bits_x, dev, self.from_buffers)
+                ent = dict(conv=c)
+                if i < u.n_body:
+                    act = getattr(u, f"quant_act{i}")
+                    s_n = self._scale(act)
+                    mm, ee = requant_table(s_x, c.s_w, s_n)
+                    ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
+                               rng=_act_range(act.activation_bit, act.quant_mode))
+                    s_x, bits_x = s_n, ent['out_bits']
+                else:
+                    ent['s_last'] = s_x
+                d['convs'].append(ent)
+            ao = u.quant_act_int32
+            s_o = self._scale(ao)
+            last = d['convs'][-1]
+            mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o)
+            last.update(m=_i32(mm, dev), e=_i32(ee, dev))
+            if d['resize']:
+                m1, e1 = requant_table(s_a, d['ident'].s_w, s_o)
+                d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
+            else:
+                m1, e1 = requant_table(s_prev, one, s_o)
+                d['m_id_s'], d['e_id_s'] = int(m1[0]), int(e1[0])
+            s_prev = s_o
+            units.append(d)
+        P['units'] = units
+        ao = m.quant_act_output
+        s8 = self._scale(ao)
+        mq, eq = requant_table(s_prev, one, s8)
+        P['out'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_act_range(ao.activation_bit, ao.quant_mode))
+        fc = m.quant_output
+        if not self.from_buffers:
+            fc.prepare(s8)
+        w = fc.weight_integer.detach().cpu().numpy()
+        nout, k = w.shape
+        if k % 64:
+            raise NotImplementedError("FC input features must be a multiple of 64")
+        nout_p = (nout + 63) // 64 * 64
+        s_fc = fc.fc_scaling_factor.detach().float().cpu()
+        fscale = np.zeros(nout_p, np.float32)
+        fscale[:nout] = (s_fc.view(1, -1) * s8.view(1, -1)).numpy().reshape(-1)  # fl(S_fc[c]*S_a)
+        b = np.zeros(nout_p, np.int64)
+        b[:nout] = np.clip(np.rint(fc.bias_integer.detach().cpu().numpy().astype(np.float64)), -2 ** 31, 2 ** 31 - 1)
+        P['fc'] = dict(w=torch.from_numpy(packing.pack_conv_weight(w.reshape(nout, k, 1, 1), 8, k, nout_p)).to(dev),
+                       bias=_i32(b, dev), fscale=torch.from_numpy(fscale).to(dev), nout=nout, nout_p=nout_p, k=k)
+
+    @staticmethod
+    def _store_bits(act):
+        if act.activation_bit <= 4:
+            if act.quant_mode != 'asymmetric':
+                raise NotImplementedError("4-bit activations are stored unsigned (asymmetric mode)")
+            return 4
+        if act.activation_bit <= 8:
+            return 8
+        raise NotImplementedError("conv inputs wider than 8 bits")
+
+    # ------------------------------------------------------------------ launch list
+    def _alloc(self, n, dtype):
+        return torch.empty(n, dtype=dtype, device=self.dev)
+
+    def _build(self, N, H, W):
+        """Allocate activation buffers for batch N and record the launch list."""
+        P, dev = self.P, self.dev
+        ops, keep = [], []
+        self.acc_taps = {}
+        sp = self.stream.cuda_stream
+        ptr = lambda t: None if t is None else t.data_ptr()
+        rdt = torch.uint16 if self.res_bits == 16 else torch.int32
+        self.x_in = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
+        # stem
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        Hp, Wp = 2 * (Ho - 1) + 7 + 1, 2 * (Wo - 1) + 8
+        Hp, Wp = max(Hp, H + 3), max(Wp + (Wp & 1), W + 3 + ((W + 3) & 1))
+        xq = torch.zeros(N * Hp * Wp * 4, dtype=torch.int8, device=dev)
+        st = P['stem']
+        stem16 = self._alloc(N * Ho * Wo * 64, torch.uint16)
+        stem_acc = self._alloc(N * Ho * Wo * 64, torch.int32) if self.keep_acc else None
+        if stem_acc is not None:
+            self.acc_taps['stem'] = (stem_acc, (N, Ho, Wo, 64))
+        ops.append(partial(_lib.call, "hawq_quantize_input", self.x_in.data_ptr(), xq.data_ptr(), N, 3, H, W, Hp, Wp,
+                           3, 3, P['inv_s_in'], -128, 127, sp))
+        c = st['conv']
+        ops.append(partial(_lib.call, "hawq_stem_conv7", xq.data_ptr(), c.w.data_ptr(), c.bias.data_ptr(),
+                           st['m'].data_ptr(), st['e'].data_ptr(), N, Hp, Wp, Ho, Wo, st['rng'][0], st['rng'][1],
+                           stem16.data_ptr(), ptr(stem_acc), sp))
+        H1, W1 = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        units = P['units']
+        u0 = units[0]
+        res = self._alloc(N * H1 * W1 * 64, torch.uint16) if not u0['resize'] else None
+        qa = self._alloc(N * H1 * W1 * 64 * u0['a_bits'] // 8, torch.uint8)
+        ops.append(partial(_lib.call, "hawq_maxpool3s2_requant", stem16.data_ptr(), N, Ho, Wo, 64, ptr(res),
+                           qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0], u0['a_rng'][1], sp))
+        keep += [xq, stem16, stem_acc, res, qa]
+        h, w = H1, W1
+        res_bits_in = 16
+        for ui, u in enumerate(units):
+            nxt = units[ui + 1] if ui + 1 < len(units) else None
+            x_in, x_bits, hin, win = qa, u['a_bits'], h, w
+            for ci, ent in enumerate(u['convs']):
+                c = ent['conv']
+                ho, wo = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
+                a = _lib.ConvArgs()
+                a.in_, a.wgt, a.bias = x_in.data_ptr(), c.w.data_ptr(), c.bias.data_ptr()
+                a.N, a.H, a.W, a.Cin, a.Cout = N, hin, win, c.cin, c.cout
+                a.KH, a.KW, a.stride, a.pad = c.kh, c.kw, c.stride, c.pad
+                a.in_bits, a.w_bits = x_bits, c.w_bits
+                a.m, a.e = ent['m'].data_ptr(), ent['e'].data_ptr()
+                a.flags = self.flags.data_ptr()
+                tap_name = f"{u['name']}.quant_convbn{ci + 1}"
+                if ci < len(u['convs']) - 1:
+                    out = self._alloc(N * ho * wo * c.cout * ent['out_bits'] // 8, torch.uint8)
+                    a.epilogue, a.relu = _lib.EPI_REQUANT, 1
+                    a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), ent['out_bits'], ent['rng'][0], ent['rng'][1]
+                    keep.append(out)
+                    x_next, xb_next = out, ent['out_bits']
+                else:
+                    a.epilogue = _lib.EPI_RESIDUAL
+                    if u['resize']:
+                        ic = u['ident']
+                        a.in2, a.wgt2, a.bias2 = qa.data_ptr(), ic.w.data_ptr(), ic.bias.data_ptr()
+                        a.H2, a.W2, a.Cin2, a.stride2 = h, w, ic.cin, ic.stride
+                        a.in2_bits, a.w2_bits = u['a_bits'], ic.w_bits
+                        a.m_id, a.e_id = u['m_id'].data_ptr(), u['e_id'].data_ptr()
+                    else:
+                        a.res_in, a.res_in_bits = res.data_ptr(), res_bits_in
+                        a.m_id_scalar, a.e_id_scalar = u['m_id_s'], u['e_id_s']
+                    need_res = (nxt is None) or (not nxt['resize'])
+                    new_res = self._alloc(N * ho * wo * c.cout, rdt) if need_res else None
+                    if new_res is not None:
+                        a.res_out, a.res_out_bits = new_res.data_ptr(), self.res_bits
+                    if nxt is not None:
+                        new_qa = self._alloc(N * ho * wo * c.cout * nxt['a_bits'] // 8, torch.uint8)
+                        a.out_q, a.out_bits = new_qa.data_ptr(), nxt['a_bits']
+                        a.q_lo, a.q_hi, a.mq, a.eq = nxt['a_rng'][0], nxt['a_rng'][1], nxt['mq'], nxt['eq']
+                    else:
+                        new_qa = None
+                    keep += [new_res, new_qa]
+                if self.keep_acc:
+                    self._add_acc_tap(ops, keep, a, tap_name, N, ho, wo, c.cout)
+                    if ci == len(u['convs']) - 1 and u['resize']:
+                        self._add_ident_tap(ops, keep, u, qa, N, h, w, ho, wo)
+                keep.append(a)
+                ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+                if ci < len(u['convs']) - 1:
+                    x_in, x_bits, hin, win = x_next, xb_next, ho, wo
+            res, qa, h, w = new_res, new_qa, ho, wo
+            res_bits_in = self.res_bits
+        cl = units[-1]['convs'][-1]['conv'].cout
+        qf = self._alloc(N * cl, torch.int8)
+        pooled = self._alloc(N * cl, torch.int32) if self.keep_acc else None
+        if pooled is not None:
+            self.acc_taps['final_pool'] = (pooled, (N, cl))
+        o = P['out']
+        ops.append(partial(_lib.call, "hawq_avgpool_requant", res.data_ptr(), self.res_bits, N, h * w, cl, qf.data_ptr(),
+                           ptr(pooled), o['mq'], o['eq'], o['rng'][0], o['rng'][1], sp))
+        fc = P['fc']
+        if fc['k'] != cl:
+            raise RuntimeError("FC input width does not match the last stage")
+        self.logits = torch.empty(N, fc['nout'], dtype=torch.float32, device=dev)
+        a = _lib.ConvArgs()
+        a.in_, a.wgt, a.bias = qf.data_ptr(), fc['w'].data_ptr(), fc['bias'].data_ptr()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = N, 1, 1, fc['k'], fc['nout_p'], 1, 1, 1, 0
+        a.in_bits, a.w_bits = 8, 8
+        a.epilogue = _lib.EPI_DEQUANT
+        a.out_f32, a.fscale, a.ldo, a.n_valid = self.logits.data_ptr(), fc['fscale'].data_ptr(), fc['nout'], fc['nout']
+        if self.keep_acc:
+            self._add_acc_tap(ops, keep, a, 'quant_output', N, 1, 1, fc['nout_p'])
+        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+        keep += [qf, pooled, a]
+        self._ops, self._keep, self._batch = ops, keep, (N, H, W)
+        self._graph = None
+
+    def _add_acc_tap(self, ops, keep, a, name, N, ho, wo, cout):
+        """Extra RAW launch of the same conv to expose its int32 accumulators (tests only)."""
+        acc = self._alloc(N * ho * wo * cout, torch.int32)
+        r = _lib.ConvArgs()
+        C.memmove(C.byref(r), C.byref(a), C.sizeof(r))
+        r.in2 = None
+        r.epilogue, r.out_acc = _lib.EPI_RAW, acc.data_ptr()
+        keep += [acc, r]
+        self.acc_taps[name] = (acc, (N, ho, wo, cout))
+        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
+
+    def _add_ident_tap(self, ops, keep, u, qa, N, h, w, ho, wo):
+        ic = u['ident']
+        acc = self._alloc(N * ho * wo * ic.cout, torch.int32)
+        r = _lib.ConvArgs()
+        r.in_, r.wgt, r.bias = qa.data_ptr(), ic.w.data_ptr(), ic.bias.data_ptr()
+        r.N, r.H, r.W, r.Cin, r.Cout, r.KH, r.KW, r.stride, r.pad = N, h, w, ic.cin, ic.cout, 1, 1, ic.stride, 0
+        r.in_bits, r.w_bits = u['a_bits'], ic.w_bits
+        r.epilogue, r.out_acc = _lib.EPI_RAW, acc.data_ptr()
+        keep += [acc, r]
+        self.acc_taps[u['name'] + ".quant_identity_convbn"] = (acc, (N, ho, wo, ic.cout))
+        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
+
+    # ------------------------------------------------------------------ execution
+    def _launch_all(self):
+        for op in self._ops:
+            op()
+
+    def __call__(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("IntegerEngine: input must be on the MI355X (no CPU path)")
+        N, Cc, H, W = x.shape
+        if Cc != 3:
+            raise ValueError("expected [N,3,H,W] images")
+        if self._batch != (N, H, W):
+            self._build(N, H, W)
+        cur = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x_in.copy_(x, non_blocking=True)
+            self.run_resident()
+        cur.wait_stream(self.stream)
+        return self.logits
+
+    def run_resident(self):
+        """One forward over ``self.x_in`` (already resident) on ``self.stream``; returns nothing."""
+        if self.use_graph:
+            if self._graph is None:
+                self._launch_all()  # warm-up outside capture (module loading, first-touch)
+                torch.cuda.synchronize(self.dev)
+                _lib.call("hawq_graph_begin", self.stream.cuda_stream)
+                try:
+                    self._launch_all()
+                finally:
+                    g = C.c_void_p()
+                    _lib.call("hawq_graph_end", self.stream.cuda_stream, C.byref(g))
+                self._graph = g
+            _lib.call("hawq_graph_launch", self._graph, self.stream.cuda_stream)
+        else:
+            self._launch_all()
+
+    def overflowed(self) -> bool:
+        """True if a uint16 residual saturated since construction (then rebuild with residual_bits=32)."""
+        return bool(self.flags.item() & 1)
+
+    def accumulators(self, name):
+        """int32 NHWC accumulators of a tapped conv (keep_accumulators=True) as an NCHW numpy array."""
+        acc, shp = self.acc_taps[name]
+        a = acc.cpu().numpy().reshape(shp)
+        return a.transpose(0, 3, 1, 2) if len(shp) == 4 else a
+
+    def __del__(self):
+        try:
+            if self._graph is not None:
+                _lib.call("hawq_graph_destroy", self._graph)
+        except Exception:
+            pass

@@ -1,0 +1,56 @@
+"""Host-side packing of integer parameters into the layouts the gfx950 kernels read.
+
+Layouts (include/hawq_mi355.h): conv weights [Cout][KH][KW][Cin] with Cin contiguous (the GEMM K
+axis), int8 or "hawq4" nibble-packed; stem weights [64][7][8][4] int8.  The reference's own
+deployment packing (tvm_benchmark/hawq_utils_resnet50.py:21-42, 111-153: OIHW->HWOI, eight
+nibbles per int32 big-endian) targets TVM's WMMA kernels and is deliberately not reused: hawq4
+is chosen so that two AND/shift ops turn one dword into two int8x4 MFMA operands in order.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def pack_hawq4(v: np.ndarray) -> np.ndarray:
+    """[..., C] integers in [-8, 15] (C % 8 == 0) -> [..., C//2] uint8, hawq4 nibble order:
+    byte k of each 8-channel group = (c_k & 15) | (c_{k+4} & 15) << 4."""
+    assert v.shape[-1] % 8 == 0
+    g = (np.asarray(v).astype(np.int64) & 0xF).astype(np.uint8).reshape(v.shape[:-1] + (v.shape[-1] // 8, 8))
+    b = g[..., 0:4] | (g[..., 4:8] << 4)
+    return np.ascontiguousarray(b.reshape(v.shape[:-1] + (v.shape[-1] // 2,)))
+
+
+def unpack_hawq4(b: np.ndarray, signed: bool = False) -> np.ndarray:
+    """Inverse of pack_hawq4: [..., C//2] uint8 -> [..., C] int32."""
+    g = np.asarray(b, np.uint8).reshape(b.shape[:-1] + (b.shape[-1] // 4, 4))
+    lo, hi = (g & 0xF).astype(np.int32), (g >> 4).astype(np.int32)
+    v = np.concatenate([lo, hi], axis=-1).reshape(b.shape[:-1] + (b.shape[-1] * 2,))
+    if signed:
+        v = np.where(v >= 8, v - 16, v)
+    return v
+
+
+def pack_conv_weight(w_int: np.ndarray, w_bits: int, cin_pad: int | None = None, cout_pad: int | None = None):
+    """OIHW integer weights -> [Cout_p][KH][KW][Cin_p] int8 bytes (w_bits 8) or hawq4 (w_bits 4);
+    channel padding is zero-filled.  Returns a flat uint8 array."""
+    w = np.rint(np.asarray(w_int, np.float64)).astype(np.int64)
+    co, ci, kh, kw = w.shape
+    cin_pad = cin_pad or ci
+    cout_pad = cout_pad or co
+    out = np.zeros((cout_pad, kh, kw, cin_pad), np.int64)
+    out[:co, :, :, :ci] = w.transpose(0, 2, 3, 1)
+    if w_bits == 8:
+        assert out.min() >= -128 and out.max() <= 127
+        return np.ascontiguousarray(out.astype(np.int8)).view(np.uint8).reshape(-1)
+    assert w_bits == 4 and out.min() >= -8 and out.max() <= 7, "4-bit weights must lie in [-8, 7]"
+    return pack_hawq4(out).reshape(-1)
+
+
+def pack_stem_weight(w_int: np.ndarray) -> np.ndarray:
+    """[64][3][7][7] integer stem weights -> [64][7][8][4] int8 (kw and c zero padded)."""
+    w = np.rint(np.asarray(w_int, np.float64)).astype(np.int64)
+    co, ci, kh, kw = w.shape
+    assert (co, kh, kw) == (64, 7, 7) and ci <= 4
+    out = np.zeros((64, 7, 8, 4), np.int8)
+    out[:, :, :7, :ci] = w.transpose(0, 2, 3, 1)
+    return np.ascontiguousarray(out).view(np.uint8).reshape(-1)

@@ -1,0 +1,178 @@
+/*
+ * hawq_mi355.h - C ABI of libhawq_mi355.so: MI355X (gfx950) integer-only kernels for the
+ * frozen forward of HAWQ's quantized ResNets.
+ *
+ * The reference (Zhen-Dong/HAWQ) has no FFI layer: its operator boundary is the Python
+ * nn.Module API of utils/quantization_utils/quant_modules.py.  Each entry point below is
+ * what a maintainer would bind (ctypes) to replace the arithmetic of
+ * one of those modules' frozen forward; the citation on each says which lines it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*.
+ *   - the library never allocates or frees activation memory and keeps no global mutable
+ *     state besides a thread-local error string; the device is the pointer's device and
+ *     work is enqueued on the hipStream_t passed as `void* stream` (0 = default stream).
+ *   - every function returns 0 on success, non-zero on error; hawq_last_error() gives
+ *     the message of the calling thread's last failure.
+ *   - activations are NHWC.  8-bit tensors are int8; 4-bit tensors are nibble-packed
+ *     "hawq4" format: within every group of 8 consecutive channels c0..c7 the 32-bit word is
+ *     (c0|c1<<8|c2<<16|c3<<24) | (c4|c5<<8|c6<<16|c7<<24)<<4  (so that two mask ops unpack it
+ *     into two int8x4 words in channel order).  16-bit residual tensors are uint16
+ *     (post-ReLU values; overflow beyond 65535 sets bit 0 of *flags and saturates) or int32.
+ *   - dyadic requantisation tables are (m, e) pairs with 0 <= m < 2^31, 1 <= e <= 62:
+ *     q = round_half_even(acc * m / 2^e)  (quant_utils.py:188-213, 404-408).
+ */
+#ifndef HAWQ_MI355_H
+#define HAWQ_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAWQ_ABI_VERSION 1
+
+const char *hawq_last_error(void);
+int hawq_abi_version(void);
+/* number of gfx950 kernels compiled into the library (sanity / "native code loaded" probe) */
+int hawq_device_ok(void);
+
+/* ---- epilogue kinds of hawq_conv2d ------------------------------------------------- */
+enum {
+    HAWQ_EPI_RAW = 0,      /* out_acc[m][c] = acc + bias               (int32 accumulators)  */
+    HAWQ_EPI_REQUANT = 1,  /* out_q = clamp(dyadic(relu?(acc+bias)))   conv -> ReLU -> QuantAct */
+    HAWQ_EPI_RESIDUAL = 2, /* residual add of two separately requantised branches, ReLU,
+                              optional next-unit QuantAct                                     */
+    HAWQ_EPI_DEQUANT = 3   /* out_f32[m][c] = float(acc+bias) * fscale[c]   (QuantLinear)     */
+};
+
+/*
+ * One fused convolution launch.  Replaces, for a frozen model,
+ *   QuantBnConv2d.forward   quant_modules.py:489-494   (integer conv + bias)
+ *   nn.ReLU                 q_resnet.py:242,246,258
+ *   QuantAct.forward/fixedpoint_fn case 0   quant_modules.py:288-293, quant_utils.py:390-413
+ *   QuantAct.forward/fixedpoint_fn case 1   quant_modules.py:294-301, quant_utils.py:416-456
+ *   (+ the next unit's block-input QuantAct, q_resnet.py:234/239)
+ *   QuantLinear.forward     quant_modules.py:125-130   (HAWQ_EPI_DEQUANT, 1x1 "conv" on [B,1,1,K])
+ * Implicit GEMM on int8 MFMA; 4-bit operands are unpacked on the way into LDS.
+ */
+typedef struct hawq_conv_args {
+    /* main branch */
+    const void *in;       /* [N][H][W][Cin]  int8, or hawq4-packed when in_bits == 4         */
+    const void *wgt;      /* [Cout][KH][KW][Cin] int8 / hawq4-packed (see hawq_pack_*)        */
+    const int32_t *bias;  /* [Cout] bias_integer                                              */
+    int32_t N, H, W, Cin, Cout, KH, KW, stride, pad;
+    int32_t in_bits, w_bits; /* 8 or 4 each (any combination)                                  */
+    /* optional second branch sharing the output grid: the identity 1x1 conv of a resize unit
+       (q_resnet.py:236).  in2 == NULL disables it. */
+    const void *in2;
+    const void *wgt2;
+    const int32_t *bias2;
+    int32_t H2, W2, Cin2, stride2, in2_bits, w2_bits;
+    int32_t epilogue; /* HAWQ_EPI_* */
+    int32_t relu;     /* apply max(.,0) to acc+bias before requantising (REQUANT only)         */
+    /* requant tables of the main branch: per output channel */
+    const int32_t *m;
+    const int32_t *e;
+    /* RESIDUAL: identity branch tables - per channel (second branch) or scalar (passthrough) */
+    const int32_t *m_id;
+    const int32_t *e_id;
+    int32_t m_id_scalar, e_id_scalar;
+    const void *res_in;   /* [M][Cout] block input carried as residual (uint16 or int32)      */
+    int32_t res_in_bits;  /* 16 or 32                                                          */
+    void *res_out;        /* [M][Cout] post-ReLU residual for the next unit, or NULL           */
+    int32_t res_out_bits; /* 16 or 32                                                          */
+    /* quantised output (REQUANT: this conv's QuantAct; RESIDUAL: next unit's QuantAct) */
+    void *out_q;          /* [M][Cout] int8 / hawq4, or NULL                                   */
+    int32_t out_bits;     /* 8 or 4                                                            */
+    int32_t q_lo, q_hi;   /* clamp range                                                       */
+    int32_t mq, eq;       /* RESIDUAL: scalar table of the next QuantAct (S_w == 1)            */
+    int32_t *out_acc;     /* RAW: [M][Cout] int32                                              */
+    float *out_f32;       /* DEQUANT: [M][ldo] fp32, only channels < n_valid are written       */
+    const float *fscale;  /* DEQUANT: [Cout]                                                   */
+    int32_t ldo, n_valid;
+    int32_t *flags;       /* device int32: bit0 = uint16 residual overflow                     */
+    int32_t tile;         /* 0 = heuristic; else tile config id (see hawq_conv2d_num_tiles)    */
+} hawq_conv_args;
+
+int hawq_conv2d(const hawq_conv_args *args, void *stream);
+int hawq_conv2d_num_tiles(void);
+
+/* QuantAct input case (quant_modules.py:271-274; quant_utils.py:73-97, 237-258):
+ * q = clamp(rint(inv_scale * x), lo, hi); fp32 NCHW [N][3][H][W] -> int8 NHWC4 with a zero
+ * border: out[N][H+2*pad_t..][..][4]; out_h/out_w are the padded extents, (pad_top, pad_left)
+ * the offset of pixel (0,0).  The border and channel 3 must have been zeroed once. */
+int hawq_quantize_input(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t out_h, int32_t out_w, int32_t pad_top, int32_t pad_left,
+                        float inv_scale, int32_t lo, int32_t hi, void *stream);
+
+/* Stem: 7x7/2 conv on the padded NHWC4 int8 image + bias, then QuantAct(16b, case 0, clamp)
+ * + ReLU fused (requant commutes with the following max-pool because it is monotone):
+ * quant_modules.py:489-494 + q_resnet.py:117-122.  wgt is [64][7][8][4] int8 (kw, c zero
+ * padded).  out16 [N][Ho][Wo][64] uint16;  out_acc (optional) raw int32. */
+int hawq_stem_conv7(const int8_t *in, const int8_t *wgt, const int32_t *bias, const int32_t *m,
+                    const int32_t *e, int32_t N, int32_t Hp, int32_t Wp, int32_t Ho, int32_t Wo,
+                    int32_t q_lo, int32_t q_hi, uint16_t *out16, int32_t *out_acc, void *stream);
+
+/* nn.MaxPool2d(3,2,1) (q_resnet.py:93,119) on the requantised stem output + the first
+ * unit's QuantAct: in [N][H][W][C] uint16 -> res_out [N][Ho][Wo][C] uint16 and
+ * out_q = clamp(dyadic(res, mq, eq)) int8/hawq4 (either may be NULL). */
+int hawq_maxpool3s2_requant(const uint16_t *in, int32_t N, int32_t H, int32_t W, int32_t C,
+                            uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq, int32_t eq,
+                            int32_t q_lo, int32_t q_hi, void *stream);
+
+/* Block-input QuantAct on a stored residual (quant_modules.py:288-293 with S_w == 1):
+ * in [n] uint16/int32 -> out int8/hawq4.  Used when the producer could not fuse it. */
+int hawq_requant_residual(const void *in, int32_t in_bits, int64_t n, void *out_q, int32_t out_bits,
+                          int32_t mq, int32_t eq, int32_t q_lo, int32_t q_hi, void *stream);
+
+/* QuantAveragePool2d + quant_act_output (quant_modules.py:596-600, quant_utils.py:334-337,
+ * q_resnet.py:129-131): in [N][HW][C] uint16/int32 (>= 0) -> floor(sum/HW) -> dyadic -> clamp
+ * -> int8 [N][C].  pooled_out (optional) receives the int32 pooled integers. */
+int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, int32_t HW, int32_t C, int8_t *out,
+                         int32_t *pooled_out, int32_t mq, int32_t eq, int32_t q_lo, int32_t q_hi,
+                         void *stream);
+
+/* ---- module-compatible (fp32 tuple convention) adapters ---------------------------------
+ * The reference modules exchange fp32 tensors holding integer*scale.  These kernels move
+ * between that convention (NCHW fp32) and the integer NHWC tensors the conv kernels use. */
+
+/* x_int = rint(x / S) (quant_modules.py:490, 126): fp32 NCHW [N][C][H][W] -> int8 / hawq4 NHWC
+ * with Cpad >= C channels (extra channels zero). */
+int hawq_f32_nchw_to_q_nhwc(const float *x, void *out, int32_t N, int32_t C, int32_t H, int32_t W,
+                            int32_t Cpad, int32_t bits, float scale, void *stream);
+/* y = float(acc) * fscale[c] (quant_modules.py:491-494): int32 NHWC [N][H][W][Cpad] -> fp32 NCHW */
+int hawq_acc_nhwc_to_f32_nchw(const int32_t *acc, float *y, int32_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t Cpad, const float *fscale, void *stream);
+/* QuantAct / fixedpoint_fn on fp32 NCHW tensors (quant_utils.py:363-456).
+ * case 0: y = clamp(dyadic(rint(z/S_a/S_w[c]), m[c], e[c])) * S_out
+ * case 1: y = (dyadic(rint(ident/S_ida/S_idw[c]), m1, e1) + dyadic(rint((z-ident)/S_a/S_w[c]), m2, e2)) * S_out
+ * per_ch = number of entries in sw/m/e (1 or C); per_ch_id likewise for the identity tables. */
+int hawq_fixedpoint_f32(const float *z, float *y, int32_t N, int32_t C, int32_t HW, float s_a,
+                        const float *s_w, const int32_t *m, const int32_t *e, int32_t per_ch,
+                        const float *ident, float s_ida, const float *s_idw, const int32_t *m_id,
+                        const int32_t *e_id, int32_t per_ch_id, float s_out, int32_t do_clamp,
+                        int32_t q_lo, int32_t q_hi, void *stream);
+/* QuantAct input case on fp32 (quant_utils.py:73-97): y = clamp(rint(inv_scale*x)) * scale */
+int hawq_fakequant_f32(const float *x, float *y, int64_t n, float inv_scale, float scale, int32_t lo,
+                       int32_t hi, void *stream);
+/* QuantAveragePool2d on fp32 NCHW (quant_modules.py:596-602): y = trunc(avg(rint(x/S)) + 0.01) * S */
+int hawq_avgpool_f32(const float *x, float *y, int32_t NC, int32_t HW, float scale, void *stream);
+
+/* ---- hipGraph helpers: capture a sequence of the launches above once, replay per batch */
+int hawq_graph_begin(void *stream);
+int hawq_graph_end(void *stream, void **graph_exec_out);
+int hawq_graph_launch(void *graph_exec, void *stream);
+int hawq_graph_destroy(void *graph_exec);
+
+/* ---- timing helper for bench.py: HIP events on the caller's stream ---------------------- */
+int hawq_event_create(void **ev);
+int hawq_event_record(void *ev, void *stream);
+int hawq_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);
+int hawq_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAWQ_MI355_H */

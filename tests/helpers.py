@@ -52,3 +52,53 @@ def reference_ckpt(fx, st):
         ck[on] = dict(scale=fx["conv_scale"][off:off + co], bias=fx["conv_bias"][off:off + co], wpatch=patch)
         off += co
     return ck
+
+
+# ------------------------------------------------------------------ GPU-side helpers
+def build_model(arch, scheme, device="cuda"):
+    from hawq_amd.api import build_quantized_resnet
+    return build_quantized_resnet(arch, scheme, seed=0).to(device)
+
+
+def conv_modules(model):
+    from hawq_amd.quant_modules import QuantBnConv2d
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, QuantBnConv2d)]
+
+
+def act_modules(model):
+    from hawq_amd.quant_modules import QuantAct
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, QuantAct)]
+
+
+def load_reference_ranges(model, fx):
+    """Set every QuantAct's frozen range from a net fixture (as a QAT checkpoint would)."""
+    import torch
+    for i, (n, m) in enumerate(act_modules(model)):
+        assert n == str(fx["act_names"][i])
+        m.x_min.fill_(float(fx["act_x_min"][i]))
+        m.x_max.fill_(float(fx["act_x_max"][i]))
+        m.compute_scale()
+        assert m.act_scaling_factor.item() == float(fx["act_scale"][i]), n
+
+
+def load_reference_integer_ckpt(model, fx):
+    """Overwrite the conv modules' integer buffers with the reference run's (scales and biases in
+    full, weight_integer = IEEE preparation + the recorded patches).  Returns #patched weights."""
+    import numpy as np
+    import torch
+    off, npatch = 0, 0
+    for li, (n, m) in enumerate(conv_modules(model)):
+        assert n == str(fx["conv_names"][li])
+        co = m.out_channels
+        dev = m.weight_integer.device
+        w = m.weight_integer.detach().cpu().numpy().copy()
+        for l, idx, val in fx["conv_wpatch"]:
+            if l == li:
+                w.reshape(-1)[idx] = val
+                npatch += 1
+        assert np.array_equal(digest(w), fx["conv_wdigest"][li]), n
+        m.weight_integer = torch.from_numpy(w).to(dev)
+        m.convbn_scaling_factor = torch.from_numpy(fx["conv_scale"][off:off + co].copy()).to(dev)
+        m.bias_integer = torch.from_numpy(fx["conv_bias"][off:off + co].astype(np.float32)).to(dev)
+        off += co
+    return npatch

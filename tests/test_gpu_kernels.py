@@ -1,0 +1,404 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle.
+Bit-exact: every comparison is np.array_equal on integers (or on fp32 produced by one exact
+multiply)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hawq_amd import _lib
+    _lib.load()
+    _lib.check(_lib.load().hawq_device_ok())
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def nhwc(x_nchw):
+    return np.ascontiguousarray(x_nchw.transpose(0, 2, 3, 1))
+
+
+def pack_act(x_nchw, bits):
+    from hawq_amd.packing import pack_hawq4
+    v = nhwc(x_nchw)
+    return v.astype(np.int8).view(np.uint8) if bits == 8 else pack_hawq4(v)
+
+
+def unpack_q(t, shape_nhwc, bits):
+    from hawq_amd.packing import unpack_hawq4
+    raw = t.cpu().numpy()
+    n, h, w, c = shape_nhwc
+    if bits == 8:
+        v = raw.view(np.int8).astype(np.int64).reshape(n, h, w, c)
+    else:
+        v = unpack_hawq4(raw.reshape(n, h, w, c // 2)).astype(np.int64)
+    return v.transpose(0, 3, 1, 2)
+
+
+def rand_tables(rng, cout, lo=2e-4, hi=3e-3):
+    """random per-channel requant ratios -> device-contract (m, e)."""
+    from hawq_amd.quant_utils import requant_table
+    r = torch.from_numpy(rng.uniform(lo, hi, cout).astype(f32))
+    return requant_table(torch.ones(1), r, torch.ones(1))
+
+
+def make_conv(rng, n, h, w, cin, cout, k, a_bits, w_bits):
+    a_lo, a_hi = (-128, 127) if a_bits == 8 else (0, 15)
+    w_lo, w_hi = (-127, 127) if w_bits == 8 else (-8, 7)
+    x = rng.integers(a_lo, a_hi + 1, (n, cin, h, w)).astype(np.int64)
+    wt = rng.integers(w_lo, w_hi + 1, (cout, cin, k, k)).astype(np.int64)
+    b = rng.integers(-20000, 20000, cout).astype(np.int64)
+    return x, wt, b
+
+
+def conv_args(lib, x, wt, b, stride, pad, a_bits, w_bits, tile=0):
+    from hawq_amd.packing import pack_conv_weight
+    n, cin, h, w = x.shape
+    cout, _, k, _ = wt.shape
+    t = dict(x=dev(pack_act(x, a_bits)), w=dev(pack_conv_weight(wt, w_bits)), b=dev(b.astype(np.int32)))
+    a = lib.ConvArgs()
+    a.in_, a.wgt, a.bias = t['x'].data_ptr(), t['w'].data_ptr(), t['b'].data_ptr()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = n, h, w, cin, cout, k, k, stride, pad
+    a.in_bits, a.w_bits, a.tile = a_bits, w_bits, tile
+    return a, t
+
+
+SHAPES = [  # n, h, w, cin, cout, k, stride, pad
+    (2, 14, 14, 64, 64, 1, 1, 0),
+    (2, 14, 14, 64, 128, 3, 1, 1),
+    (1, 14, 14, 128, 256, 1, 2, 0),
+    (2, 15, 13, 64, 64, 3, 2, 1),
+    (1, 7, 7, 256, 128, 3, 1, 1),      # M = 49: ragged pixel tile
+    (3, 9, 9, 192, 64, 1, 1, 0),       # Cin not a power of two
+    (1, 1, 1, 512, 192, 1, 1, 0),      # M = 1 (the FC shape)
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("bits", [(8, 8), (4, 4), (8, 4), (4, 8)])
+def test_conv_raw_accumulators(lib, orc, shape, bits):
+    n, h, w, cin, cout, k, stride, pad = shape
+    rng = np.random.default_rng(hash((shape, bits)) % 2 ** 32)
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
+    ref = orc.conv2d(x, wt, b, stride, pad)
+    for tile in range(0, lib.load().hawq_conv2d_num_tiles() + 1):
+        a, keep = conv_args(lib, x, wt, b, stride, pad, *bits, tile=tile)
+        out = torch.full((ref.size,), -7, dtype=torch.int32, device='cuda')
+        a.epilogue, a.out_acc = lib.EPI_RAW, out.data_ptr()
+        lib.call("hawq_conv2d", C.byref(a), stream())
+        got = out.cpu().numpy().reshape(n, ref.shape[2], ref.shape[3], cout).transpose(0, 3, 1, 2)
+        assert np.array_equal(got, ref), f"tile {tile}"
+
+
+def test_conv_identity_weights_asymmetric(lib):
+    """A = I check with an asymmetric activation tensor: catches operand transposes/permutations."""
+    n, h, w, c = 1, 8, 8, 64
+    x = (np.arange(n * c * h * w).reshape(n, c, h, w) % 251 - 125).astype(np.int64)
+    wt = np.zeros((c, c, 1, 1), np.int64)
+    wt[np.arange(c), np.arange(c), 0, 0] = 1
+    a, keep = conv_args(lib, x, wt, np.zeros(c, np.int64), 1, 0, 8, 8)
+    out = torch.empty(n * h * w * c, dtype=torch.int32, device='cuda')
+    a.epilogue, a.out_acc = lib.EPI_RAW, out.data_ptr()
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    assert np.array_equal(out.cpu().numpy().reshape(n, h, w, c).transpose(0, 3, 1, 2), x)
+
+
+@pytest.mark.parametrize("out_bits", [8, 4])
+@pytest.mark.parametrize("bits", [(8, 8), (4, 4)])
+def test_conv_requant_epilogue(lib, orc, bits, out_bits):
+    rng = np.random.default_rng(5)
+    n, h, w, cin, cout, k = 2, 12, 12, 128, 128, 3
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
+    acc = orc.conv2d(x, wt, b, 1, 1)
+    m, e = rand_tables(rng, cout, 2e-5 if bits[0] == 8 else 2e-3, 3e-4 if bits[0] == 8 else 2e-2)
+    m[0], e[0] = 1 << 30, 32  # ratio 1/4: produces exact .5 ties
+    lo, hi = (-128, 127) if out_bits == 8 else (0, 15)
+    ref = orc.dyadic(np.maximum(acc, 0), m, e, (lo, hi))
+    a, keep = conv_args(lib, x, wt, b, 1, 1, *bits)
+    md, ed = dev(m), dev(e)
+    out = torch.zeros(ref.size * out_bits // 8, dtype=torch.uint8, device='cuda')
+    a.epilogue, a.relu, a.m, a.e = lib.EPI_REQUANT, 1, md.data_ptr(), ed.data_ptr()
+    a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), out_bits, lo, hi
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    assert np.array_equal(unpack_q(out, (n, h, w, cout), out_bits), ref)
+    # without ReLU, symmetric clamp
+    if out_bits == 8:
+        a.relu = 0
+        lib.call("hawq_conv2d", C.byref(a), stream())
+        assert np.array_equal(unpack_q(out, (n, h, w, cout), 8), orc.dyadic(acc, m, e, (lo, hi)))
+
+
+@pytest.mark.parametrize("res_bits", [16, 32])
+@pytest.mark.parametrize("dual", [False, True])
+def test_conv_residual_epilogue(lib, orc, dual, res_bits):
+    rng = np.random.default_rng(11 + dual)
+    n, h, w, cin, cout = 2, 14, 14, 64, 256
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 1, 8, 8)
+    acc = orc.conv2d(x, wt, b, 1, 0)
+    m2, e2 = rand_tables(rng, cout, 1e-3, 4e-2)
+    a, keep = conv_args(lib, x, wt, b, 1, 0, 8, 8)
+    if dual:  # identity 1x1 stride-2 conv on a 2x larger grid
+        x2, w2, b2 = make_conv(rng, n, 2 * h, 2 * w, 128, cout, 1, 8, 8)
+        acc_id = orc.conv2d(x2, w2, b2, 2, 0)
+        m1, e1 = rand_tables(rng, cout, 1e-3, 4e-2)
+        idq = orc.dyadic(acc_id, m1, e1)
+        from hawq_amd.packing import pack_conv_weight
+        keep.update(x2=dev(pack_act(x2, 8)), w2=dev(pack_conv_weight(w2, 8)), b2=dev(b2.astype(np.int32)),
+                    m1=dev(m1), e1=dev(e1))
+        a.in2, a.wgt2, a.bias2 = keep['x2'].data_ptr(), keep['w2'].data_ptr(), keep['b2'].data_ptr()
+        a.H2, a.W2, a.Cin2, a.stride2, a.in2_bits, a.w2_bits = 2 * h, 2 * w, 128, 2, 8, 8
+        a.m_id, a.e_id = keep['m1'].data_ptr(), keep['e1'].data_ptr()
+    else:
+        res = rng.integers(0, 60000, (n, cout, h, w)).astype(np.int64)
+        from hawq_amd.quant_utils import requant_table
+        m1, e1 = requant_table(torch.tensor([0.37]), torch.ones(1), torch.ones(1))
+        idq = orc.dyadic(res, m1, e1)
+        keep['res'] = dev(nhwc(res).astype(np.uint16 if res_bits == 16 else np.int32))
+        a.res_in, a.res_in_bits = keep['res'].data_ptr(), res_bits
+        a.m_id_scalar, a.e_id_scalar = int(m1[0]), int(e1[0])
+    ref_res = np.maximum(orc.dyadic(acc, m2, e2) + idq, 0)
+    assert ref_res.max() < 65536
+    from hawq_amd.quant_utils import requant_table
+    mq, eq = requant_table(torch.tensor([0.0039]), torch.ones(1), torch.ones(1))
+    ref_q = orc.dyadic(ref_res, mq, eq, (0, 127))
+    md, ed = dev(m2), dev(e2)
+    flags = torch.zeros(1, dtype=torch.int32, device='cuda')
+    out_res = torch.zeros(ref_res.size, dtype=torch.uint16 if res_bits == 16 else torch.int32, device='cuda')
+    out_q = torch.zeros(ref_res.size, dtype=torch.uint8, device='cuda')
+    a.epilogue, a.m, a.e, a.flags = lib.EPI_RESIDUAL, md.data_ptr(), ed.data_ptr(), flags.data_ptr()
+    a.res_out, a.res_out_bits = out_res.data_ptr(), res_bits
+    a.out_q, a.out_bits, a.q_lo, a.q_hi, a.mq, a.eq = out_q.data_ptr(), 8, 0, 127, int(mq[0]), int(eq[0])
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    got = out_res.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2)
+    assert np.array_equal(got, ref_res)
+    assert np.array_equal(unpack_q(out_q, (n, h, w, cout), 8), ref_q)
+    assert flags.item() == 0
+
+
+def test_residual_uint16_overflow_sets_flag(lib, orc):
+    rng = np.random.default_rng(3)
+    n, h, w, cin, cout = 1, 8, 8, 64, 64
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 1, 8, 8)
+    a, keep = conv_args(lib, x, wt, b, 1, 0, 8, 8)
+    res = np.full((n, h, w, cout), 65000, np.uint16)
+    keep['res'] = dev(res)
+    m2 = np.full(cout, 1 << 30, np.int32)
+    e2 = np.full(cout, 31, np.int32)  # ratio 1/2
+    md, ed = dev(m2), dev(e2)
+    flags = torch.zeros(1, dtype=torch.int32, device='cuda')
+    out_res = torch.zeros(n * h * w * cout, dtype=torch.uint16, device='cuda')
+    a.epilogue, a.m, a.e, a.flags = lib.EPI_RESIDUAL, md.data_ptr(), ed.data_ptr(), flags.data_ptr()
+    a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = keep['res'].data_ptr(), 16, 1 << 30, 30  # ratio 1
+    a.res_out, a.res_out_bits = out_res.data_ptr(), 16
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    acc = orc.conv2d(x, wt, b, 1, 0)
+    expect_ovf = (np.maximum(orc.dyadic(acc, m2.astype(np.int64), e2) + 65000, 0) > 65535).any()
+    assert bool(flags.item() & 1) == bool(expect_ovf) and expect_ovf
+
+
+def test_bad_arguments_return_errors(lib):
+    a = lib.ConvArgs()
+    rc = lib.load().hawq_conv2d(C.byref(a), None)
+    assert rc != 0 and b"hawq_conv2d" in lib.load().hawq_last_error()
+    with pytest.raises(RuntimeError):
+        lib.call("hawq_quantize_input", None, None, 1, 3, 8, 8, 8, 8, 0, 0, 1.0, -128, 127, None)
+
+
+def test_quantize_input_and_stem(lib, orc):
+    from hawq_amd.packing import pack_stem_weight
+    rng = np.random.default_rng(9)
+    n, hh, ww = 2, 38, 46
+    x = rng.normal(0, 1.2, (n, 3, hh, ww)).astype(f32)
+    x.reshape(-1)[:6] = [0.5, 1.5, 2.5, -0.5, 1e9, -1e9]
+    scale = f32(1.0)
+    q_ref = orc.quantize_f32(x, scale, 8)
+    ho, wo = (hh + 6 - 7) // 2 + 1, (ww + 6 - 7) // 2 + 1
+    hp, wp = max(2 * (ho - 1) + 8, hh + 3), max(2 * (wo - 1) + 8, ww + 4)
+    wp += wp & 1
+    xq = torch.zeros(n * hp * wp * 4, dtype=torch.int8, device='cuda')
+    xd = dev(x)
+    lib.call("hawq_quantize_input", xd.data_ptr(), xq.data_ptr(), n, 3, hh, ww, hp, wp, 3, 3, float(f32(1) / scale),
+             -128, 127, stream())
+    got = xq.cpu().numpy().reshape(n, hp, wp, 4)[:, 3:3 + hh, 3:3 + ww, :3].transpose(0, 3, 1, 2)
+    assert np.array_equal(got, q_ref)
+    wt = rng.integers(-127, 128, (64, 3, 7, 7)).astype(np.int64)
+    b = rng.integers(-30000, 30000, 64).astype(np.int64)
+    acc = orc.conv2d(q_ref, wt, b, 2, 3)
+    m, e = rand_tables(rng, 64, 2e-3, 4e-2)
+    ref16 = np.maximum(orc.dyadic(acc, m, e, (-32768, 32767)), 0)
+    wd, bd, md, ed = dev(pack_stem_weight(wt)), dev(b.astype(np.int32)), dev(m), dev(e)
+    out16 = torch.zeros(n * ho * wo * 64, dtype=torch.uint16, device='cuda')
+    out_acc = torch.zeros(n * ho * wo * 64, dtype=torch.int32, device='cuda')
+    lib.call("hawq_stem_conv7", xq.data_ptr(), wd.data_ptr(), bd.data_ptr(), md.data_ptr(), ed.data_ptr(), n, hp, wp,
+             ho, wo, -32768, 32767, out16.data_ptr(), out_acc.data_ptr(), stream())
+    assert np.array_equal(out_acc.cpu().numpy().reshape(n, ho, wo, 64).transpose(0, 3, 1, 2), acc)
+    assert np.array_equal(out16.cpu().numpy().astype(np.int64).reshape(n, ho, wo, 64).transpose(0, 3, 1, 2), ref16)
+    # max-pool + first QuantAct
+    from hawq_amd.quant_utils import requant_table
+    mq, eq = requant_table(torch.tensor([0.0041]), torch.ones(1), torch.ones(1))
+    pooled = orc.maxpool(ref16, 3, 2, 1)
+    h1, w1 = pooled.shape[2:]
+    for bits, (lo, hi) in ((8, (-128, 127)), (4, (0, 15))):
+        res = torch.zeros(pooled.size, dtype=torch.uint16, device='cuda')
+        qo = torch.zeros(pooled.size * bits // 8, dtype=torch.uint8, device='cuda')
+        lib.call("hawq_maxpool3s2_requant", out16.data_ptr(), n, ho, wo, 64, res.data_ptr(), qo.data_ptr(), bits,
+                 int(mq[0]), int(eq[0]), lo, hi, stream())
+        assert np.array_equal(res.cpu().numpy().astype(np.int64).reshape(n, h1, w1, 64).transpose(0, 3, 1, 2), pooled)
+        assert np.array_equal(unpack_q(qo, (n, h1, w1, 64), bits), orc.dyadic(pooled, mq, eq, (lo, hi)))
+        q2 = torch.zeros_like(qo)
+        lib.call("hawq_requant_residual", res.data_ptr(), 16, pooled.size, q2.data_ptr(), bits, int(mq[0]), int(eq[0]),
+                 lo, hi, stream())
+        assert torch.equal(q2, qo)
+
+
+@pytest.mark.parametrize("res_bits", [16, 32])
+def test_avgpool_requant(lib, orc, res_bits):
+    from hawq_amd.quant_utils import requant_table
+    rng = np.random.default_rng(21)
+    n, c = 3, 512
+    x = rng.integers(0, 45000, (n, c, 7, 7)).astype(np.int64)
+    x[0, 0] = 3
+    x[0, 1] = 5
+    x[0, 1, 6, 6] = 4
+    pooled = orc.avgpool_trunc(x)
+    mq, eq = requant_table(torch.tensor([0.0038]), torch.ones(1), torch.ones(1))
+    ref = orc.dyadic(pooled, mq, eq, (-128, 127))
+    xin = dev(nhwc(x).astype(np.uint16 if res_bits == 16 else np.int32))
+    out = torch.zeros(n * c, dtype=torch.int8, device='cuda')
+    pd = torch.zeros(n * c, dtype=torch.int32, device='cuda')
+    lib.call("hawq_avgpool_requant", xin.data_ptr(), res_bits, n, 49, c, out.data_ptr(), pd.data_ptr(), int(mq[0]),
+             int(eq[0]), -128, 127, stream())
+    assert np.array_equal(pd.cpu().numpy().reshape(n, c), pooled)
+    assert np.array_equal(out.cpu().numpy().astype(np.int64).reshape(n, c), ref)
+
+
+def test_dequant_epilogue_fc(lib, orc):
+    rng = np.random.default_rng(2)
+    bsz, k, nout = 5, 512, 1000
+    x = rng.integers(-128, 128, (bsz, k)).astype(np.int64)
+    wt = rng.integers(-127, 128, (nout, k)).astype(np.int64)
+    b = rng.integers(-50000, 50000, nout).astype(np.int64)
+    acc = orc.linear(x, wt, b)
+    fs = rng.uniform(1e-5, 1e-4, nout).astype(f32)
+    ref = (acc.astype(f32) * fs.reshape(1, -1)).astype(f32)
+    from hawq_amd.packing import pack_conv_weight
+    wp = dev(pack_conv_weight(wt.reshape(nout, k, 1, 1), 8, k, 1024))
+    bp = np.zeros(1024, np.int32)
+    bp[:nout] = b
+    fsp = np.zeros(1024, f32)
+    fsp[:nout] = fs
+    xd, bd, fd = dev(x.astype(np.int8)), dev(bp), dev(fsp)
+    out = torch.full((bsz, nout), float('nan'), device='cuda')
+    a = lib.ConvArgs()
+    a.in_, a.wgt, a.bias = xd.data_ptr(), wp.data_ptr(), bd.data_ptr()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = bsz, 1, 1, k, 1024, 1, 1, 1, 0
+    a.in_bits, a.w_bits, a.epilogue = 8, 8, lib.EPI_DEQUANT
+    a.out_f32, a.fscale, a.ldo, a.n_valid = out.data_ptr(), fd.data_ptr(), nout, nout
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------- fp32-convention adapters vs live-reference KATs
+def test_fixedpoint_fn_matches_reference_kats():
+    from hawq_amd.quant_utils import fixedpoint_fn
+    kf = H.load("kat_functions.npz")
+    for tag in ["rand8", "rand4", "rand16", "tie8", "tie16"]:
+        bits, sym = kf[f"fp0_{tag}_bits"]
+        mode = "symmetric" if sym else "asymmetric"
+        t = lambda k: torch.from_numpy(kf[k]).cuda()
+        y = fixedpoint_fn.apply(t(f"fp0_{tag}_z"), int(bits), mode, t(f"fp0_{tag}_sout"), 0, t(f"fp0_{tag}_sa"),
+                                t(f"fp0_{tag}_sw"))
+        assert np.array_equal(y.cpu().numpy(), kf[f"fp0_{tag}_y"]), tag
+        for itag in ("pass", "conv"):
+            k = f"fp1_{tag}_{itag}"
+            ident = t(k + "_ident")
+            y1 = fixedpoint_fn.apply(t(f"fp0_{tag}_z") + ident, int(bits), mode, t(f"fp0_{tag}_sout"), 1,
+                                     t(f"fp0_{tag}_sa"), t(f"fp0_{tag}_sw"), ident, t(k + "_sida"), t(k + "_sidw"))
+            assert np.array_equal(y1.cpu().numpy(), kf[k + "_y"]), k
+
+
+def test_quant_functions_match_reference_kats():
+    from hawq_amd.quant_utils import AsymmetricQuantFunction, SymmetricQuantFunction
+    kf = H.load("kat_functions.npz")
+    x = torch.from_numpy(kf["q_x"]).cuda()
+    for tag in "abc":
+        s = torch.from_numpy(kf[f"symq_{tag}_scale"]).cuda()
+        assert np.array_equal(SymmetricQuantFunction.apply(x, 8, s).cpu().numpy(), kf[f"symq_{tag}_8"])
+        assert np.array_equal(SymmetricQuantFunction.apply(x, 4, s).cpu().numpy(), kf[f"symq_{tag}_4"])
+        assert np.array_equal(AsymmetricQuantFunction.apply(x, 4, s).cpu().numpy(), kf[f"asymq_{tag}_4"])
+
+
+def test_modules_match_reference_kats():
+    """QuantBnConv2d / QuantLinear / QuantAveragePool2d / QuantAct module forwards (fp32 tuple
+    convention) against tensors recorded from the live reference modules."""
+    from hawq_amd import quant_modules as qm
+    km = H.load("kat_modules.npz")
+    for tag in ["c3", "c1s2", "c3s2", "c7"]:
+        g = lambda k: torch.from_numpy(km[f"conv_{tag}_{k}"])
+        cin, cout, k, stride, pad, bits, hw = km[f"conv_{tag}_cfg"]
+        conv = torch.nn.Conv2d(int(cin), int(cout), int(k), int(stride), int(pad), bias=False)
+        bn = torch.nn.BatchNorm2d(int(cout))
+        with torch.no_grad():
+            conv.weight.copy_(g("w")); bn.weight.copy_(g("gamma")); bn.bias.copy_(g("beta"))
+            bn.running_mean.copy_(g("mean")); bn.running_var.copy_(g("var"))
+        m = qm.QuantBnConv2d(weight_bit=int(bits), bias_bit=32, per_channel=True, fix_BN=True)
+        m.set_param(conv, bn)
+        m.fix()
+        m = m.cuda().eval()
+        s_a = g("s_a").cuda()
+        y, s_w = m(((g("q") * g("s_a")).cuda(), s_a))
+        if np.array_equal(s_w.cpu().numpy(), km[f"conv_{tag}_s_w"]):  # else: sqrt quirk
+            assert np.array_equal(m.weight_integer.cpu().numpy(), km[f"conv_{tag}_weight_integer"])
+            assert np.array_equal(m.bias_integer.cpu().numpy(), km[f"conv_{tag}_bias_integer"])
+            # reference fp32 output carries un-rounded x/S_a; the recovered integers must agree
+            rec = lambda t: torch.round(t / s_a.view(1, -1, 1, 1).cpu() / g("s_w").view(1, -1, 1, 1))
+            assert torch.equal(rec(y.cpu()), rec(g("y"))), tag
+    lin = torch.nn.Linear(64, 10)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(km["lin_w"])); lin.bias.copy_(torch.from_numpy(km["lin_b"]))
+    m = qm.QuantLinear(weight_bit=8, bias_bit=32, per_channel=True)
+    m.set_param(lin)
+    m = m.cuda()
+    s_a = torch.from_numpy(km["lin_s_a"]).cuda()
+    y = m(torch.from_numpy(km["lin_q"]).cuda() * s_a, s_a)
+    assert np.array_equal(y.cpu().numpy(), km["lin_y"])
+    assert np.array_equal(m.weight_integer.cpu().numpy(), km["lin_weight_integer"])
+    p = qm.QuantAveragePool2d(7, 1)
+    s = torch.from_numpy(km["pool_s"]).cuda()
+    y, _ = p(torch.from_numpy(km["pool_q"]).cuda() * s, s)
+    assert np.array_equal(y.cpu().numpy(), km["pool_y"])
+    a = qm.QuantAct(activation_bit=8)
+    a.x_min += float(km["act_in_rng"][0])
+    a.x_max += float(km["act_in_rng"][1])
+    a.fix()
+    a = a.cuda()
+    y, s = a(torch.from_numpy(km["act_in_x"]).cuda())
+    assert np.array_equal(s.cpu().numpy(), km["act_in_s"]) and np.array_equal(y.cpu().numpy(), km["act_in_y"])
+
+
+def test_cpu_tensors_raise():
+    from hawq_amd import quant_modules as qm
+    a = qm.QuantAct(activation_bit=8)
+    with pytest.raises(RuntimeError):
+        a(torch.randn(1, 3, 4, 4))
