@@ -76,13 +76,18 @@ class QuantAct(Module):
         self.fix_flag = False
 
     def compute_scale(self):
-        """act_scaling_factor from the frozen range (quant_modules.py:262-270)."""
+        """act_scaling_factor from the frozen range (quant_modules.py:262-270).  Evaluated on the
+        host in IEEE binary32: torch's GPU kernels turn `tensor / python_scalar` into a multiply by
+        the rounded reciprocal, which would make the scale (and everything downstream) differ
+        from the CPU reference by an ulp."""
+        dev = self.x_min.device
+        x_min, x_max = self.x_min.detach().float().cpu(), self.x_max.detach().float().cpu()
         if self.quant_mode == 'symmetric':
-            self.act_scaling_factor = symmetric_linear_quantization_params(self.activation_bit, self.x_min,
-                                                                           self.x_max, False)
+            self.act_scaling_factor = symmetric_linear_quantization_params(self.activation_bit, x_min, x_max,
+                                                                           False).to(dev)
         elif self.quant_mode == 'asymmetric':
-            self.act_scaling_factor, self.act_zero_point = asymmetric_linear_quantization_params(
-                self.activation_bit, self.x_min, self.x_max, True)
+            scale, zp = asymmetric_linear_quantization_params(self.activation_bit, x_min, x_max, True)
+            self.act_scaling_factor, self.act_zero_point = scale.to(dev), zp.to(dev)
         else:
             raise ValueError("unknown quant mode: {}".format(self.quant_mode))
         return self.act_scaling_factor
