@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Throughput bench of the MI355X integer forward (BASELINE.json metric: images/s, ResNet50
+W8A8 at batch 128 per GPU; W4A4 / mixed / ResNet18 reported in ``extra``).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--arch resnet50] [--scheme uniform8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one frozen forward of one batch: fp32 images resident in HBM -> fp32 logits in HBM
+(one hipGraph launch of the fused integer plan); with N > 1 every rank processes its own
+batch of 128 (weak scaling, batch-sharded data parallelism) and each step ends with one RCCL
+all_gather of the [128,1000] logits (the reference's DataParallel gather, quant_train.py:358).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def setup_workload(arch, scheme, batch, dev, seed):
+    from hawq_amd.api import build_quantized_resnet, calibrate
+    from hawq_amd.engine import IntegerEngine
+    from hawq_amd.skeleton import synthetic_images
+
+    model = build_quantized_resnet(arch, scheme, seed=0).to(dev)
+    calibrate(model, synthetic_images(8, seed=0).to(dev))
+    eng = IntegerEngine(model, use_graph=True)
+    x = synthetic_images(batch, seed=seed).to(dev)
+    eng(x)  # allocate, warm up, capture the hipGraph
+    return model, eng, x
+
+
+def timed_steps(eng, steps, warmup, world, gathered):
+    """W untimed + K timed steps on the engine stream; returns (wall seconds, GPU ms per step)."""
+    import torch.distributed as dist
+    from hawq_amd import _lib
+
+    sp = eng.stream.cuda_stream
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    _lib.call("hawq_event_create", C.byref(ev0))
+    _lib.call("hawq_event_create", C.byref(ev1))
+
+    def step():
+        eng.run_resident()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, eng.logits)
+
+    with torch.cuda.stream(eng.stream):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.call("hawq_event_record", ev0, sp)
+        for _ in range(steps):
+            step()
+        _lib.call("hawq_event_record", ev1, sp)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    ms = C.c_float()
+    _lib.call("hawq_event_elapsed_ms", ev0, ev1, C.byref(ms))
+    _lib.call("hawq_event_destroy", ev0)
+    _lib.call("hawq_event_destroy", ev1)
+    return t1 - t0, ms.value / steps
+
+
+def cpu_baseline(model, x, gpu_logits, sample=16):
+    """Time the CPU fake-quant port (oracle/fakequant_port.py) on a bounded sample of the same
+    workload and use its logits as a parity check of the GPU result."""
+    from oracle import fakequant_port, oracle
+
+    st = oracle.extract_float_state(model)
+    xs = x[:sample].cpu()
+    fakequant_port.forward(st, xs[:2])  # warm-up (thread pools, oneDNN primitives)
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        y = fakequant_port.forward(st, xs)
+    dt = time.perf_counter() - t0
+    parity = bool(torch.equal(y, gpu_logits[:sample].cpu()))
+    return dict(value=round(reps * sample / dt, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{reps} forwards of batch {sample} of the same workload (torch-CPU fp32 fake-quant port of "
+                       f"the reference path, {dt:.1f} s)", gpu_logits_bit_equal=parity)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--scheme", default="uniform8")
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / per-kernel table")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hawq_amd import roofline
+
+    model, eng, x = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1 + rank)
+    gathered = torch.empty(world * args.batch, eng.logits.shape[1], device=dev) if world > 1 else None
+    wall, gpu_ms = timed_steps(eng, args.steps, args.warmup, world, gathered)
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    overflow = eng.overflowed()
+    ms_per_step = wall / args.steps * 1e3
+    value = world * args.batch * args.steps / wall
+
+    out = None
+    if rank == 0:
+        alg = roofline.algorithmic_bytes(args.arch, args.scheme, args.batch)
+        macs = roofline.macs(args.arch, args.scheme, args.batch)
+        gbs = alg / (gpu_ms * 1e-3) / 1e9
+        out = {
+            "metric": "images/sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": f"{args.arch}_{args.scheme}_b{args.batch}", "arch": args.arch,
+                       "scheme": args.scheme, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+                       "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
+                       "residual_uint16_overflow": overflow},
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "one hipGraph launch = whole forward of one batch",
+                         "gpu_ms_per_launch": round(gpu_ms, 4), "algorithmic_bytes_per_launch": alg,
+                         "mfma_frac": round(2 * macs / (gpu_ms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)},
+        }
+        if not args.no_extra and world == 1:
+            ops = eng.profile_ops()
+            tot = sum(ms for _, ms in ops)
+            rows = {r["name"]: r for r in roofline.layer_table(args.arch, args.scheme)}
+            top = sorted(ops, key=lambda t: -t[1])[:8]
+            out["roofline"]["eager_sum_ms"] = round(tot, 4)
+            out["roofline"]["top_launches"] = [{"name": n, "ms": round(ms, 4)} for n, ms in top]
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, x, eng.logits)
+        else:
+            out["cpu_baseline"] = None
+    if not args.no_extra and world == 1 and rank == 0:
+        extra = {}
+        del eng, model
+        torch.cuda.empty_cache()
+        for arch, scheme in (("resnet50", "uniform4"), ("resnet50", "bops_0.5"), ("resnet18", "uniform8")):
+            if (arch, scheme) == (args.arch, args.scheme):
+                continue
+            m2, e2, x2 = setup_workload(arch, scheme, args.batch, dev, seed=1)
+            w2, g2 = timed_steps(e2, max(10, args.steps // 2), 5, 1, None)
+            alg2 = roofline.algorithmic_bytes(arch, scheme, args.batch)
+            extra[f"{arch}_{scheme}_b{args.batch}"] = {
+                "images_per_s": round(args.batch * max(10, args.steps // 2) / w2, 1), "gpu_ms": round(g2, 4),
+                "hbm_frac": round(alg2 / (g2 * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4), "overflow": e2.overflowed()}
+            del m2, e2, x2
+            torch.cuda.empty_cache()
+        out["extra"] = extra
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,21 @@ def _act_range(bits, mode):
     return 0, 2 ** bits - 1
 
 
+class _OpList(list):
+    """launch list; ``names[i]`` labels ``self[i]`` (set ``next_name`` before appending)."""
+
+    def __init__(self):
+        super().__init__()
+        self.names = []
+        self.next_name = None
+
+    def append(self, fn):
+        name = self.next_name or (fn.args[0] if hasattr(fn, "args") else "op")
+        self.names.append(name)
+        self.next_name = None
+        super().append(fn)
+
+
 class _Conv:
     """Device-resident parameters of one QuantBnConv2d."""
 
@@ -189,7 +204,7 @@ class IntegerEngine:
     def _build(self, N, H, W):
         """Allocate activation buffers for batch N and record the launch list."""
         P, dev = self.P, self.dev
-        ops, keep = [], []
+        ops, keep = _OpList(), []
         self.acc_taps = {}
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
@@ -268,6 +283,7 @@ class IntegerEngine:
                     if ci == len(u['convs']) - 1 and u['resize']:
                         self._add_ident_tap(ops, keep, u, qa, N, h, w, ho, wo)
                 keep.append(a)
+                ops.next_name = tap_name + ("+identity" if (a.in2 is not None) else "")
                 ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
                 if ci < len(u['convs']) - 1:
                     x_in, x_bits, hin, win = x_next, xb_next, ho, wo
@@ -293,6 +309,7 @@ class IntegerEngine:
         a.out_f32, a.fscale, a.ldo, a.n_valid = self.logits.data_ptr(), fc['fscale'].data_ptr(), fc['nout'], fc['nout']
         if self.keep_acc:
             self._add_acc_tap(ops, keep, a, 'quant_output', N, 1, 1, fc['nout_p'])
+        ops.next_name = "quant_output"
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
         keep += [qf, pooled, a]
         self._ops, self._keep, self._batch = ops, keep, (N, H, W)
@@ -358,6 +375,29 @@ class IntegerEngine:
             _lib.call("hawq_graph_launch", self._graph, self.stream.cuda_stream)
         else:
             self._launch_all()
+
+    def profile_ops(self, repeats: int = 5):
+        """Per-launch durations (ms, median of ``repeats``) measured with HIP events around each
+        eager launch on the engine stream.  Returns [(name, ms)] in launch order."""
+        sp = self.stream.cuda_stream
+        evs = []
+        for _ in range(len(self._ops) + 1):
+            e = C.c_void_p()
+            _lib.call("hawq_event_create", C.byref(e))
+            evs.append(e)
+        samples = [[] for _ in self._ops]
+        for _ in range(repeats):
+            _lib.call("hawq_event_record", evs[0], sp)
+            for i, op in enumerate(self._ops):
+                op()
+                _lib.call("hawq_event_record", evs[i + 1], sp)
+            for i in range(len(self._ops)):
+                ms = C.c_float()
+                _lib.call("hawq_event_elapsed_ms", evs[i], evs[i + 1], C.byref(ms))
+                samples[i].append(ms.value)
+        for e in evs:
+            _lib.call("hawq_event_destroy", e)
+        return [(n, sorted(v)[len(v) // 2]) for n, v in zip(self._ops.names, samples)]
 
     def overflowed(self) -> bool:
         """True if a uint16 residual saturated since construction (then rebuild with residual_bits=32)."""

@@ -196,3 +196,36 @@ def test_ieee_prep_differs_from_reference_only_by_sqrt_quirk(arch, scheme):
         ndiff += int((s != ref).sum())
     assert len(fx["conv_wpatch"]) <= 4
     assert ndiff < 0.02 * off
+
+
+def _set_ranges_from_fixture(st, fx):
+    order = {str(n): i for i, n in enumerate(fx["act_names"])}
+
+    def put(a, name):
+        i = order[name]
+        a["x_min"] = np.array([fx["act_x_min"][i]], f32)
+        a["x_max"] = np.array([fx["act_x_max"][i]], f32)
+
+    put(st["quant_input"], "quant_input")
+    put(st["quant_act_int32"], "quant_act_int32")
+    for u in st["units"]:
+        for k in ("quant_act", "quant_act1", "quant_act2", "quant_act_int32"):
+            if k in u:
+                put(u[k], u["name"] + "." + k)
+    put(st["quant_act_output"], "quant_act_output")
+    return st
+
+
+@pytest.mark.parametrize("arch,scheme", [("resnet18", "uniform8"), ("resnet50", "uniform4"), ("resnet50", "bops_0.5")])
+def test_fakequant_port_matches_reference(arch, scheme):
+    """The torch-CPU fake-quant port that bench.py times as ``cpu_baseline`` computes the
+    reference's logits (same top-1; bit-equal where the sqrt quirk does not intervene)."""
+    import torch
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import fakequant_port
+
+    fx = H.net_fixture(arch, scheme)
+    st = _set_ranges_from_fixture(_build_state(arch, scheme), fx)
+    y = fakequant_port.forward(st, synthetic_images(2, 0)).numpy()
+    assert np.array_equal(y.argmax(1), fx["top1"])
+    assert np.array_equal(y, fx["logits"])
