@@ -29,17 +29,50 @@ void hawq_set_error(const char *fmt, ...);
     } while (0)
 
 // ---- dyadic requantisation ---------------------------------------------------------------
-// q = round_half_even(v * m / 2^e), exact in 64-bit integers (|v| < 2^31, 0 <= m < 2^31,
-// 1 <= e <= 62).  Restates fixedpoint_fn's float64 emulation (quant_utils.py:404-408):
-// half-up via the +2^(e-1) bias folded into the 64-bit multiply-add, then the exact-tie case
-// (all e low bits of the biased product zero) is pulled back to the even neighbour.
-__device__ __forceinline__ int32_t dyadic_rne(int32_t v, int32_t m, int32_t e) {
+// Table entry = (m, ek) with ek = e | k << 8:   q = round_half_even(((v << k) * m) / 2^e),
+// 0 <= m < 2^31, 1 <= e <= 62, k >= 0 small (host guarantees |v << k| < 2^31).  The pre-shift k
+// lets the host lift every e to >= 33 so that the conv epilogues can use the high-word fast path
+// below; mathematically (v*2^k*m)/2^(e_orig+k) is the same rational, so rounding is unchanged.
+// Restates fixedpoint_fn's float64 emulation (quant_utils.py:404-408) in exact integers:
+// half-up via +2^(e-1), then an exact tie (all e low bits of the biased product zero) is pulled
+// back to the even neighbour.
+__device__ __forceinline__ int32_t dyadic_rne(int32_t v, int32_t m, int32_t ek) {
+    const int e = ek & 0xff, k = ek >> 8;
     const long long half = 1ll << (e - 1);
-    const long long t = (long long)v * (long long)m + half;
+    const long long t = (long long)(v << k) * (long long)m + half;
     long long f = t >> e;
     const long long mask = (1ll << e) - 1;
     if ((t & mask) == 0) f &= ~1ll;
     return (int32_t)f;
+}
+
+// Fast path for e >= 33 (s = e - 32 in [1,30]): the rounding bias 2^(e-1) only touches the high
+// word, the quotient is an arithmetic shift of the high word, and a tie needs BOTH the low word
+// and the s low bits of the high word to vanish.  `z` (0 iff tie) is min-accumulated by the
+// caller; the rare wave that sees z == 0 redoes its batch with dyadic_rne.
+struct DyCh {  // per-channel constants derived once from (m, ek)
+    int m, s, k, half;
+};
+__device__ __forceinline__ DyCh dy_prepare(int m, int ek) {
+    DyCh c;
+    c.m = m;
+    c.s = (ek & 0xff) - 32;
+    c.k = ek >> 8;
+    c.half = 1 << (c.s - 1);
+    return c;
+}
+__device__ __forceinline__ int32_t dyadic_fast(int32_t v, const DyCh &c, unsigned &zmin) {
+    const long long p = (long long)(v << c.k) * (long long)c.m;
+    const int hi = (int)(p >> 32) + c.half;
+    const unsigned z = __builtin_amdgcn_ubfe((unsigned)hi, 0u, (unsigned)c.s) | (unsigned)p;
+    zmin = z < zmin ? z : zmin;
+    return hi >> c.s;
+}
+__device__ __forceinline__ int32_t dyadic_fix(int32_t q, int32_t v, const DyCh &c) {  // tie -> even
+    const long long p = (long long)(v << c.k) * (long long)c.m;
+    const int hi = (int)(p >> 32) + c.half;
+    const unsigned z = __builtin_amdgcn_ubfe((unsigned)hi, 0u, (unsigned)c.s) | (unsigned)p;
+    return z == 0 ? (q & ~1) : q;
 }
 
 __device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) {

@@ -211,51 +211,26 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
     }
 }
 
-template <class C>
+// BITS: 0 = decide at run time (generic fallback, costs registers), else (a_bits << 4) | w_bits.
+template <class C, int BITS>
 __device__ __forceinline__ void run_segment(v16i (&acc)[C::CT][C::PT], const uint8_t *in, const uint8_t *wgt,
                                             int a_bits, int w_bits, int H, int W, int Cin, int KH, int KW,
                                             int stride, int pad, int Ho, int Wo, int M, int Cout, int m0, int c0,
                                             char *smem) {
-    if (a_bits == 8 && w_bits == 8)
+    if (BITS == 0x88 || (BITS == 0 && a_bits == 8 && w_bits == 8))
         gemm_segment<C, 8, 8>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
-    else if (a_bits == 4 && w_bits == 4)
+    else if (BITS == 0x44 || (BITS == 0 && a_bits == 4 && w_bits == 4))
         gemm_segment<C, 4, 4>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
-    else if (a_bits == 8 && w_bits == 4)
+    else if (BITS == 0x84 || (BITS == 0 && a_bits == 8 && w_bits == 4))
         gemm_segment<C, 8, 4>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
     else
         gemm_segment<C, 4, 8>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
 }
 
-__device__ __forceinline__ void load16(const int32_t *p, int (&v)[16]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v4i t = reinterpret_cast<const v4i *>(p)[i];
-        v[4 * i] = t.x;
-        v[4 * i + 1] = t.y;
-        v[4 * i + 2] = t.z;
-        v[4 * i + 3] = t.w;
-    }
-}
+__device__ __forceinline__ v4i ld4(const int32_t *p) { return *reinterpret_cast<const v4i *>(p); }
 
-// store 16 clamped ints as int8 (16 B) or hawq4 (8 B) at channel offset ch of pixel pix
-__device__ __forceinline__ void store_q16(void *out, int bits, size_t elem, const int (&q)[16]) {
-    if (bits == 8) {
-        v4i w;
-        w.x = (int)pack4_i8(q[0], q[1], q[2], q[3]);
-        w.y = (int)pack4_i8(q[4], q[5], q[6], q[7]);
-        w.z = (int)pack4_i8(q[8], q[9], q[10], q[11]);
-        w.w = (int)pack4_i8(q[12], q[13], q[14], q[15]);
-        *reinterpret_cast<v4i *>((char *)out + elem) = w;
-    } else {
-        v2i w;
-        w.x = (int)pack8_u4(&q[0]);
-        w.y = (int)pack8_u4(&q[8]);
-        *reinterpret_cast<v2i *>((char *)out + (elem >> 1)) = w;
-    }
-}
-
-template <class C, int EPI, bool DUAL>
-__global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
+template <class C, int EPI, bool DUAL, int BITS, int BITS2>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
     // each XCD a contiguous run of pixel tiles that share the same weight tile in its L2.
@@ -277,120 +252,199 @@ __global__ __launch_bounds__(256) void conv_kernel(const ConvP p) {
         for (int q = 0; q < C::PT; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
-    run_segment<C>(acc, p.in, p.wgt, p.in_bits, p.w_bits, p.H, p.W, p.Cin, p.KH, p.KW, p.stride, p.pad, p.Ho,
-                   p.Wo, p.M, p.Cout, m0, c0, smem);
+    run_segment<C, BITS>(acc, p.in, p.wgt, p.in_bits, p.w_bits, p.H, p.W, p.Cin, p.KH, p.KW, p.stride, p.pad, p.Ho,
+                         p.Wo, p.M, p.Cout, m0, c0, smem);
     v16i acc2[DUAL ? C::CT : 1][DUAL ? C::PT : 1];
-    if (DUAL) {
+    if constexpr (DUAL) {
 #pragma unroll
         for (int c = 0; c < C::CT; ++c)
 #pragma unroll
             for (int q = 0; q < C::PT; ++q)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[DUAL ? c : 0][DUAL ? q : 0][r] = 0;
-        run_segment<C>(reinterpret_cast<v16i(&)[C::CT][C::PT]>(acc2), p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2,
-                       p.W2, p.Cin2, 1, 1, p.stride2, 0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
+                for (int r = 0; r < 16; ++r) acc2[c][q][r] = 0;
+        run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2, 0,
+                              p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
     }
 
     // ---------------------------------------------------------------- epilogue
+    // Lane (l31, h) owns pixel l31 of each pixel tile and channels ch..ch+15 of each channel tile.
+    // Channels are processed in 4 groups of 4 to keep the per-channel constants in few registers.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_m = wave % C::WM, wave_c = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
+    int pix[C::PT];
+#pragma unroll
+    for (int q = 0; q < C::PT; ++q) pix[q] = m0 + wave_m * (C::PT * 32) + q * 32 + l31;
+
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
         const int ch = c0 + wave_c * (C::CT * 32) + c * 32 + h * 16;  // first of this lane's 16 channels
-        int bias[16], mm[16], ee[16], bias2[16], m1[16], e1[16];
-        load16(p.bias + ch, bias);
-        if (EPI == HAWQ_EPI_REQUANT || EPI == HAWQ_EPI_RESIDUAL) {
-            load16(p.m + ch, mm);
-            load16(p.e + ch, ee);
-        }
-        if (DUAL) {
-            load16(p.bias2 + ch, bias2);
-            load16(p.m_id + ch, m1);
-            load16(p.e_id + ch, e1);
-        }
+        if constexpr (EPI == HAWQ_EPI_RAW) {
 #pragma unroll
-        for (int q = 0; q < C::PT; ++q) {
-            const int pix = m0 + wave_m * (C::PT * 32) + q * 32 + l31;
-            if (pix >= p.M) continue;
-            const size_t elem = (size_t)pix * p.Cout + ch;
-            int v[16];
+            for (int q = 0; q < C::PT; ++q) {
+                if (pix[q] >= p.M) continue;
+                const size_t elem = (size_t)pix[q] * p.Cout + ch;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[c][q][r] + bias[r];
-            if (EPI == HAWQ_EPI_RAW) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v4i w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-                    reinterpret_cast<v4i *>(p.out_acc + elem)[i] = w;
+                for (int g = 0; g < 4; ++g) {
+                    const v4i b = ld4(p.bias + ch + 4 * g);
+                    v4i w = {acc[c][q][4 * g] + b.x, acc[c][q][4 * g + 1] + b.y, acc[c][q][4 * g + 2] + b.z,
+                             acc[c][q][4 * g + 3] + b.w};
+                    reinterpret_cast<v4i *>(p.out_acc + elem)[g] = w;
                 }
-            } else if (EPI == HAWQ_EPI_DEQUANT) {
+            }
+        } else if constexpr (EPI == HAWQ_EPI_DEQUANT) {
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q) {
+                if (pix[q] >= p.M) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (ch + r < p.n_valid) p.out_f32[(size_t)pix * p.ldo + ch + r] = (float)v[r] * p.fscale[ch + r];
-            } else if (EPI == HAWQ_EPI_REQUANT) {
-                int qv[16];
+                    if (ch + r < p.n_valid)
+                        p.out_f32[(size_t)pix[q] * p.ldo + ch + r] =
+                            (float)(acc[c][q][r] + p.bias[ch + r]) * p.fscale[ch + r];
+            }
+        } else {
+            constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
+            // residual inputs of this channel tile are fetched first so that their latency overlaps
+            // the table loads and the requant arithmetic
+            v4i rin[C::PT][(RES && !DUAL) ? 4 : 1];
+            if constexpr (RES && !DUAL) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int x = p.relu ? max(v[r], 0) : v[r];
-                    qv[r] = clampi(dyadic_rne(x, mm[r], ee[r]), p.q_lo, p.q_hi);
-                }
-                store_q16(p.out_q, p.out_bits, elem, qv);
-            } else {  // RESIDUAL
-                int idv[16];
-                if (DUAL) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        idv[r] = dyadic_rne(acc2[DUAL ? c : 0][DUAL ? q : 0][r] + bias2[r], m1[r], e1[r]);
-                } else {
+                for (int q = 0; q < C::PT; ++q) {
+                    const size_t elem = (size_t)(pix[q] < p.M ? pix[q] : 0) * p.Cout + ch;
                     if (p.res_in_bits == 16) {
                         const v4i *src = reinterpret_cast<const v4i *>((const uint16_t *)p.res_in + elem);
-                        v4i a = src[0], b = src[1];
-                        const int w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            idv[2 * i] = w[i] & 0xffff;
-                            idv[2 * i + 1] = (unsigned)w[i] >> 16;
-                        }
+                        rin[q][0] = src[0];
+                        rin[q][1] = src[1];
                     } else {
-                        load16((const int32_t *)p.res_in + elem, idv);
-                    }
+                        const v4i *src = reinterpret_cast<const v4i *>((const int32_t *)p.res_in + elem);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) idv[r] = dyadic_rne(idv[r], p.m_id_s, p.e_id_s);
-                }
-                int o[16];
-                bool ovf = false;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o[r] = max(dyadic_rne(v[r], mm[r], ee[r]) + idv[r], 0);  // no clamp: quant_utils.py:456
-                    ovf |= o[r] > 65535;
-                }
-                if (p.res_out) {
-                    if (p.res_out_bits == 16) {
-                        if (ovf) atomicOr(p.flags, 1);
-                        v4i a, b;
-                        int w[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            w[i] = min(o[2 * i], 65535) | (min(o[2 * i + 1], 65535) << 16);
-                        a.x = w[0], a.y = w[1], a.z = w[2], a.w = w[3];
-                        b.x = w[4], b.y = w[5], b.z = w[6], b.w = w[7];
-                        v4i *dst = reinterpret_cast<v4i *>((uint16_t *)p.res_out + elem);
-                        dst[0] = a;
-                        dst[1] = b;
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            v4i w = {o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
-                            reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[i] = w;
-                        }
+                        for (int i = 0; i < 4; ++i) rin[q][i] = src[i];
                     }
                 }
-                if (p.out_q) {
-                    int qv[16];
+            }
+            int qpack[C::PT][4];             // 16 x int8, or 2 dwords of hawq4 in [0..1]
+            int rpack[C::PT][RES ? 16 : 1];  // uint16 pairs in [0..7] or 16 x int32
+            bool ovf = false;
+            const DyCh dids = dy_prepare(p.m_id_s, p.e_id_s), dq = dy_prepare(p.mq, p.eq);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) qv[r] = clampi(dyadic_rne(o[r], p.mq, p.eq), p.q_lo, p.q_hi);
-                    store_q16(p.out_q, p.out_bits, elem, qv);
+            for (int g = 0; g < 4; ++g) {
+                const v4i b4 = ld4(p.bias + ch + 4 * g), m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
+                const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                const int mraw[4] = {m4.x, m4.y, m4.z, m4.w}, eraw[4] = {e4.x, e4.y, e4.z, e4.w};
+                DyCh dm[4], di[4];
+                int bb2[4] = {0, 0, 0, 0}, m2raw[4] = {0, 0, 0, 0}, e2raw[4] = {33, 33, 33, 33};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dm[j] = dy_prepare(mraw[j], eraw[j]);
+                if constexpr (DUAL) {
+                    const v4i b2 = ld4(p.bias2 + ch + 4 * g), mi = ld4(p.m_id + ch + 4 * g),
+                              ei = ld4(p.e_id + ch + 4 * g);
+                    bb2[0] = b2.x, bb2[1] = b2.y, bb2[2] = b2.z, bb2[3] = b2.w;
+                    m2raw[0] = mi.x, m2raw[1] = mi.y, m2raw[2] = mi.z, m2raw[3] = mi.w;
+                    e2raw[0] = ei.x, e2raw[1] = ei.y, e2raw[2] = ei.z, e2raw[3] = ei.w;
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) di[j] = DUAL ? dy_prepare(m2raw[j], e2raw[j]) : dids;
+#pragma unroll
+                for (int q = 0; q < C::PT; ++q) {
+                    int v[4], idin[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, qv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[c][q][4 * g + j] + bb[j];
+                    unsigned zmin = 0xffffffffu;
+                    if constexpr (!RES) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (p.relu) v[j] = max(v[j], 0);
+                            qv[j] = dyadic_fast(v[j], dm[j], zmin);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(zmin == 0)) {  // an exact tie in this wave: redo exactly
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) qv[j] = dyadic_rne(v[j], mraw[j], eraw[j]);
+                        }
+                    } else {
+                        if constexpr (DUAL) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) idin[j] = acc2[c][q][4 * g + j] + bb2[j];
+                        } else if (p.res_in_bits == 16) {
+                            const int w0 = rin[q][g >> 1][(g & 1) * 2], w1 = rin[q][g >> 1][(g & 1) * 2 + 1];
+                            idin[0] = w0 & 0xffff, idin[1] = (int)((unsigned)w0 >> 16);
+                            idin[2] = w1 & 0xffff, idin[3] = (int)((unsigned)w1 >> 16);
+                        } else {
+                            const v4i w = rin[q][(RES && !DUAL) ? g : 0];
+                            idin[0] = w.x, idin[1] = w.y, idin[2] = w.z, idin[3] = w.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int a = dyadic_fast(v[j], dm[j], zmin);
+                            const int b = dyadic_fast(idin[j], di[j], zmin);
+                            o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
+                            qv[j] = dyadic_fast(o[j], dq, zmin);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(zmin == 0)) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int a = dyadic_rne(v[j], mraw[j], eraw[j]);
+                                const int b = DUAL ? dyadic_rne(idin[j], m2raw[j], e2raw[j])
+                                                   : dyadic_rne(idin[j], p.m_id_s, p.e_id_s);
+                                o[j] = max(a + b, 0);
+                                qv[j] = dyadic_rne(o[j], p.mq, p.eq);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ovf |= o[j] > 65535;
+                        if (p.res_out_bits == 16) {
+                            rpack[q][RES ? 2 * g : 0] = min(o[0], 65535) | (min(o[1], 65535) << 16);
+                            rpack[q][RES ? 2 * g + 1 : 0] = min(o[2], 65535) | (min(o[3], 65535) << 16);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) rpack[q][RES ? 4 * g + j : 0] = o[j];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qv[j] = clampi(qv[j], p.q_lo, p.q_hi);
+                    const int w = (int)pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+                    if (p.out_bits == 8) {
+                        qpack[q][g] = w;
+                    } else if (g & 1) {  // hawq4: low nibbles = channels 0-3 of the 8-group, high = 4-7
+                        qpack[q][g >> 1] |= w << 4;
+                    } else {
+                        qpack[q][g >> 1] = w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q) {
+                if (pix[q] >= p.M) continue;
+                const size_t elem = (size_t)pix[q] * p.Cout + ch;
+                if constexpr (RES) {
+                    if (p.res_out) {
+                        if (p.res_out_bits == 16) {
+                            v4i *dst = reinterpret_cast<v4i *>((uint16_t *)p.res_out + elem);
+                            v4i a = {rpack[q][0], rpack[q][1], rpack[q][2], rpack[q][3]};
+                            v4i b = {rpack[q][4], rpack[q][5], rpack[q][6], rpack[q][7]};
+                            dst[0] = a;
+                            dst[1] = b;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                v4i w = {rpack[q][4 * i], rpack[q][4 * i + 1], rpack[q][4 * i + 2],
+                                         rpack[q][4 * i + 3]};
+                                reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[i] = w;
+                            }
+                        }
+                    }
+                }
+                if (!RES || p.out_q) {
+                    if (p.out_bits == 8) {
+                        v4i w = {qpack[q][0], qpack[q][1], qpack[q][2], qpack[q][3]};
+                        *reinterpret_cast<v4i *>((char *)p.out_q + elem) = w;
+                    } else {
+                        v2i w = {qpack[q][0], qpack[q][1]};
+                        *reinterpret_cast<v2i *>((char *)p.out_q + (elem >> 1)) = w;
+                    }
+                }
+            }
+            if constexpr (RES) {
+                if (ovf && p.res_out && p.res_out_bits == 16) atomicOr(p.flags, 1);
             }
         }
     }
@@ -403,17 +457,26 @@ using T3 = Cfg<128, 64, 2, 2>;
 constexpr int NUM_TILES = 4;
 
 typedef void (*KernelFn)(const ConvP);
+// single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
+// dual-branch (RESIDUAL + identity conv): {run-time, 88/88, 44/44, 88/44, 44/88}
 struct TileInfo {
     int BM, BN, lds;
-    KernelFn fn[5];  // RAW, REQUANT, RESIDUAL, DEQUANT, RESIDUAL+DUAL
+    KernelFn single[4][3];
+    KernelFn dual[5];
 };
-#define TILE_ENTRY(T)                                                                                   \
-    {                                                                                                   \
-        T::BM, T::BN, T::LDS_BYTES, {                                                                   \
-            conv_kernel<T, HAWQ_EPI_RAW, false>, conv_kernel<T, HAWQ_EPI_REQUANT, false>,               \
-                conv_kernel<T, HAWQ_EPI_RESIDUAL, false>, conv_kernel<T, HAWQ_EPI_DEQUANT, false>,      \
-                conv_kernel<T, HAWQ_EPI_RESIDUAL, true>                                                 \
-        }                                                                                               \
+#define SINGLE_ROW(T, E) \
+    { conv_kernel<T, E, false, 0, 0>, conv_kernel<T, E, false, 0x88, 0>, conv_kernel<T, E, false, 0x44, 0> }
+#define TILE_ENTRY(T)                                                                                          \
+    {                                                                                                          \
+        T::BM, T::BN, T::LDS_BYTES,                                                                            \
+            {SINGLE_ROW(T, HAWQ_EPI_RAW), SINGLE_ROW(T, HAWQ_EPI_REQUANT), SINGLE_ROW(T, HAWQ_EPI_RESIDUAL),   \
+             SINGLE_ROW(T, HAWQ_EPI_DEQUANT)},                                                                 \
+        {                                                                                                      \
+            conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0, 0>, conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x88, 0x88>, \
+                conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x44, 0x44>,                                           \
+                conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x88, 0x44>,                                           \
+                conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x44, 0x88>                                            \
+        }                                                                                                      \
     }
 const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0), TILE_ENTRY(T1), TILE_ENTRY(T2), TILE_ENTRY(T3)};
 
@@ -474,6 +537,23 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.out_q = a->out_q, p.out_bits = a->out_bits, p.q_lo = a->q_lo, p.q_hi = a->q_hi, p.mq = a->mq, p.eq = a->eq;
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
     p.flags = a->flags;
+    // scalar dyadic tables use the conv epilogues' fast path: e must be in [33, 62] (see requant_table)
+    auto e_ok = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; };
+    if (a->epilogue == HAWQ_EPI_RESIDUAL) {
+        if (a->out_q) {
+            HAWQ_REQUIRE(e_ok(a->eq) && a->mq >= 0, "hawq_conv2d: (mq, eq) must satisfy 33 <= e <= 62");
+        } else {
+            p.mq = 0, p.eq = 33;
+        }
+        if (!dual) {
+            HAWQ_REQUIRE(e_ok(a->e_id_scalar) && a->m_id_scalar >= 0,
+                         "hawq_conv2d: (m_id_scalar, e_id_scalar) must satisfy 33 <= e <= 62");
+        } else {
+            p.m_id_s = 0, p.e_id_s = 33;
+        }
+    } else {
+        p.mq = 0, p.eq = 33, p.m_id_s = 0, p.e_id_s = 33;
+    }
     int slot = -1;
     switch (a->epilogue) {
         case HAWQ_EPI_RAW:
@@ -493,7 +573,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
                          "hawq_conv2d: res_out_bits 16 (with flags) or 32");
             HAWQ_REQUIRE(!a->out_q || a->out_bits == 8 || a->out_bits == 4, "hawq_conv2d: out_bits must be 4 or 8");
             HAWQ_REQUIRE(a->res_out || a->out_q, "hawq_conv2d: RESIDUAL needs res_out and/or out_q");
-            slot = dual ? 4 : 2;
+            slot = 2;
             break;
         case HAWQ_EPI_DEQUANT:
             HAWQ_REQUIRE(a->out_f32 && a->fscale && a->ldo > 0, "hawq_conv2d: DEQUANT needs out_f32, fscale, ldo");
@@ -507,7 +587,15 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (p.Cout % kTiles[tile].BN != 0) tile = 2;
     const TileInfo &ti = kTiles[tile];
     const int grid = ((p.M + ti.BM - 1) / ti.BM) * (p.Cout / ti.BN);
-    hipLaunchKernelGGL(ti.fn[slot], dim3(grid), dim3(256), ti.lds, (hipStream_t)stream, p);
+    auto variant = [](int ab, int wb) { return ab == 8 && wb == 8 ? 1 : (ab == 4 && wb == 4 ? 2 : 0); };
+    KernelFn fn;
+    if (dual) {
+        const int v1 = variant(p.in_bits, p.w_bits), v2 = variant(p.in2_bits, p.w2_bits);
+        fn = (v1 == 0 || v2 == 0) ? ti.dual[0] : ti.dual[v1 == v2 ? v1 : (v1 == 1 ? 3 : 4)];
+    } else {
+        fn = ti.single[slot][variant(p.in_bits, p.w_bits)];
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), ti.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -28,6 +28,9 @@ from . import _lib, packing
 from .quant_utils import requant_table
 
 
+RES_VBITS = 20  # residual / pooled values are 16-bit-ish (uint16 storage saturates at 65535)
+
+
 def _i32(arr, dev):
     return torch.from_numpy(np.ascontiguousarray(arr, np.int32)).to(dev)
 
@@ -73,6 +76,12 @@ class _Conv:
         if self.cin % 64 == 0 and self.cout % 64 == 0:
             self.w = torch.from_numpy(packing.pack_conv_weight(w_int, self.w_bits)).to(dev)
         self.bias = _i32(self.b_host, dev)
+        # exact per-channel bound on |accumulator| -> bit length, for the requant pre-shift check
+        amax = 128 if in_bits == 8 else 15
+        bound = np.abs(np.rint(w_int.astype(np.float64))).reshape(self.cout, -1).sum(1) * amax + np.abs(self.b_host)
+        self.vbits = np.array([int(b).bit_length() for b in bound], np.int64)
+        if (self.vbits > 31).any():
+            raise ValueError("int32 accumulator overflow is possible for this layer")
 
 
 class IntegerEngine:
@@ -124,7 +133,7 @@ class IntegerEngine:
         sc.w = torch.from_numpy(packing.pack_stem_weight(sc.w_host)).to(dev)
         a0 = m.quant_act_int32
         s0 = self._scale(a0)
-        mm, ee = requant_table(s_in, sc.s_w, s0)
+        mm, ee = requant_table(s_in, sc.s_w, s0, vbits=sc.vbits)
         P['stem'] = dict(conv=sc, m=_i32(mm, dev), e=_i32(ee, dev), rng=_act_range(a0.activation_bit, a0.quant_mode))
         s_prev = s0
         units = []
@@ -134,7 +143,7 @@ class IntegerEngine:
             s_a = self._scale(qa)
             d['a_bits'] = self._store_bits(qa)
             d['a_rng'] = _act_range(qa.activation_bit, qa.quant_mode)
-            mq, eq = requant_table(s_prev, one, s_a)
+            mq, eq = requant_table(s_prev, one, s_a, vbits=RES_VBITS)
             d['mq'], d['eq'] = int(mq[0]), int(eq[0])
             if d['resize']:
                 d['ident'] = _Conv(u.quant_identity_convbn, s_a, d['a_bits'], dev, self.from_buffers)
@@ -146,7 +155,7 @@ class IntegerEngine:
                 if i < u.n_body:
                     act = getattr(u, f"quant_act{i}")
                     s_n = self._scale(act)
-                    mm, ee = requant_table(s_x, c.s_w, s_n)
+                    mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
                                rng=_act_range(act.activation_bit, act.quant_mode))
                     s_x, bits_x = s_n, ent['out_bits']
@@ -156,20 +165,20 @@ class IntegerEngine:
             ao = u.quant_act_int32
             s_o = self._scale(ao)
             last = d['convs'][-1]
-            mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o)
+            mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o, vbits=last['conv'].vbits)
             last.update(m=_i32(mm, dev), e=_i32(ee, dev))
             if d['resize']:
-                m1, e1 = requant_table(s_a, d['ident'].s_w, s_o)
+                m1, e1 = requant_table(s_a, d['ident'].s_w, s_o, vbits=d['ident'].vbits)
                 d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
             else:
-                m1, e1 = requant_table(s_prev, one, s_o)
+                m1, e1 = requant_table(s_prev, one, s_o, vbits=RES_VBITS)
                 d['m_id_s'], d['e_id_s'] = int(m1[0]), int(e1[0])
             s_prev = s_o
             units.append(d)
         P['units'] = units
         ao = m.quant_act_output
         s8 = self._scale(ao)
-        mq, eq = requant_table(s_prev, one, s8)
+        mq, eq = requant_table(s_prev, one, s8, vbits=RES_VBITS)
         P['out'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_act_range(ao.activation_bit, ao.quant_mode))
         fc = m.quant_output
         if not self.from_buffers:

@@ -60,12 +60,16 @@ def batch_frexp(inputs):
             torch.from_numpy(np.asarray(e, np.float64)).to(inputs.device).view(shape))
 
 
-def requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_factor):
-    """Device-ready (m, e) int32 numpy tables of fixedpoint_fn (quant_utils.py:394-404):
-    r = dbl(fl(S_a*S_w)) / dbl(fl(S_out)).  Normalised for the kernels' contract
-    0 <= m < 2^31, 1 <= e <= 62 without changing any rounded result:
+def requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_factor, vbits=24, lift=True):
+    """Device-ready (m, ek) int32 numpy tables of fixedpoint_fn (quant_utils.py:394-404):
+    r = dbl(fl(S_a*S_w)) / dbl(fl(S_out)),  (m, e) = batch_frexp(r),  ek = e' | k << 8  with
+    q = round_half_even(((v << k) * m) / 2^e').  Normalised for the kernels' contract
+    0 <= m < 2^31, 1 <= e' <= 62 without changing any rounded result:
       m == 2^31 (mantissa rounded up to 1.0)  ->  (2^30, e-1)   same rational m/2^e
-      e  > 62                                  ->  (0, 1)        |acc*m/2^e| < 1/2 -> 0 either way
+      e  > 62                                  ->  (0, 33)       |v*m/2^e| < 1/2 -> 0 either way
+      lift: e < 33  ->  k = 33 - e, e' = 33   same rational (v*2^k*m)/2^(e+k); lets the conv
+            epilogues use their high-word fast path.  Needs |v| < 2^vbits with vbits + k <= 31
+            (``vbits`` scalar or per-channel array: an upper bound on the bit length of |v|).
     """
     a = pre_act_scaling_factor.detach().reshape(-1).cpu().double()
     w = pre_weight_scaling_factor.detach().reshape(-1).cpu().double()
@@ -78,10 +82,17 @@ def requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_f
     m[top] = 1 << 30
     e[top] -= 1
     tiny = e > 62
-    m[tiny], e[tiny] = 0, 1
+    m[tiny], e[tiny] = 0, 33
+    k = np.zeros_like(e)
+    if lift:
+        k = np.maximum(33 - e, 0)
+        e = e + k
     if (e < 1).any():
         raise ValueError("requantisation ratio >= 2^30 is not supported by the integer kernels")
-    return m.astype(np.int32), e.astype(np.int32)
+    if (np.broadcast_to(np.asarray(vbits, np.int64), e.shape) + k > 31).any():
+        raise ValueError("requantisation ratio too large for the accumulator width "
+                         f"(needs pre-shift {int(k.max())} on values of up to {np.max(vbits)} bits)")
+    return m.astype(np.int32), (e | (k << 8)).astype(np.int32)
 
 
 # --------------------------------------------------------------------- quantise-from-float
@@ -173,7 +184,7 @@ class fixedpoint_fn:
         dev = z.device
         s_a = float(pre_act_scaling_factor.detach().reshape(-1)[0].item())
         s_w = pre_weight_scaling_factor.detach().reshape(-1).float()
-        m, e = requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_factor)
+        m, e = requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_factor, lift=False)
         md, ed, swd = _dev_i32(m, dev), _dev_i32(e, dev), s_w.to(dev).contiguous()
         y = torch.empty_like(z)
         if case == 0:
@@ -184,7 +195,8 @@ class fixedpoint_fn:
             ident = identity.contiguous().float()
             s_ida = float(identity_scaling_factor.detach().reshape(-1)[0].item())
             s_idw = identity_weight_scaling_factor.detach().reshape(-1).float()
-            m1, e1 = requant_table(identity_scaling_factor, identity_weight_scaling_factor, z_scaling_factor)
+            m1, e1 = requant_table(identity_scaling_factor, identity_weight_scaling_factor, z_scaling_factor,
+                                   lift=False)
             m1d, e1d, sidwd = _dev_i32(m1, dev), _dev_i32(e1, dev), s_idw.to(dev).contiguous()
             _lib.call("hawq_fixedpoint_f32", z.data_ptr(), y.data_ptr(), N, Cc, HW, s_a, swd.data_ptr(),
                       md.data_ptr(), ed.data_ptr(), int(m.size), ident.data_ptr(), s_ida, sidwd.data_ptr(),

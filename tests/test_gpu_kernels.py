@@ -56,6 +56,12 @@ def unpack_q(t, shape_nhwc, bits):
     return v.transpose(0, 3, 1, 2)
 
 
+def odyadic(orc, acc, m, ek, clamp=None):
+    """oracle dyadic on a device-format (m, e|k<<8) table: (v*2^k*m)/2^e == v*m/2^(e-k)."""
+    ek = np.asarray(ek, np.int64)
+    return orc.dyadic(acc, np.asarray(m, np.int64), ((ek & 0xff) - (ek >> 8)).astype(np.int32), clamp)
+
+
 def rand_tables(rng, cout, lo=2e-4, hi=3e-3):
     """random per-channel requant ratios -> device-contract (m, e)."""
     from hawq_amd.quant_utils import requant_table
@@ -132,9 +138,9 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits):
     x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
     acc = orc.conv2d(x, wt, b, 1, 1)
     m, e = rand_tables(rng, cout, 2e-5 if bits[0] == 8 else 2e-3, 3e-4 if bits[0] == 8 else 2e-2)
-    m[0], e[0] = 1 << 30, 32  # ratio 1/4: produces exact .5 ties
+    m[0], e[0] = 1 << 30, 33 | (1 << 8)  # ratio 1/4 (e=32 lifted by k=1): produces exact .5 ties
     lo, hi = (-128, 127) if out_bits == 8 else (0, 15)
-    ref = orc.dyadic(np.maximum(acc, 0), m, e, (lo, hi))
+    ref = odyadic(orc, np.maximum(acc, 0), m, e, (lo, hi))
     a, keep = conv_args(lib, x, wt, b, 1, 1, *bits)
     md, ed = dev(m), dev(e)
     out = torch.zeros(ref.size * out_bits // 8, dtype=torch.uint8, device='cuda')
@@ -146,7 +152,7 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits):
     if out_bits == 8:
         a.relu = 0
         lib.call("hawq_conv2d", C.byref(a), stream())
-        assert np.array_equal(unpack_q(out, (n, h, w, cout), 8), orc.dyadic(acc, m, e, (lo, hi)))
+        assert np.array_equal(unpack_q(out, (n, h, w, cout), 8), odyadic(orc, acc, m, e, (lo, hi)))
 
 
 @pytest.mark.parametrize("res_bits", [16, 32])
@@ -162,7 +168,7 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits):
         x2, w2, b2 = make_conv(rng, n, 2 * h, 2 * w, 128, cout, 1, 8, 8)
         acc_id = orc.conv2d(x2, w2, b2, 2, 0)
         m1, e1 = rand_tables(rng, cout, 1e-3, 4e-2)
-        idq = orc.dyadic(acc_id, m1, e1)
+        idq = odyadic(orc, acc_id, m1, e1)
         from hawq_amd.packing import pack_conv_weight
         keep.update(x2=dev(pack_act(x2, 8)), w2=dev(pack_conv_weight(w2, 8)), b2=dev(b2.astype(np.int32)),
                     m1=dev(m1), e1=dev(e1))
@@ -173,15 +179,15 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits):
         res = rng.integers(0, 60000, (n, cout, h, w)).astype(np.int64)
         from hawq_amd.quant_utils import requant_table
         m1, e1 = requant_table(torch.tensor([0.37]), torch.ones(1), torch.ones(1))
-        idq = orc.dyadic(res, m1, e1)
+        idq = odyadic(orc, res, m1, e1)
         keep['res'] = dev(nhwc(res).astype(np.uint16 if res_bits == 16 else np.int32))
         a.res_in, a.res_in_bits = keep['res'].data_ptr(), res_bits
         a.m_id_scalar, a.e_id_scalar = int(m1[0]), int(e1[0])
-    ref_res = np.maximum(orc.dyadic(acc, m2, e2) + idq, 0)
+    ref_res = np.maximum(odyadic(orc, acc, m2, e2) + idq, 0)
     assert ref_res.max() < 65536
     from hawq_amd.quant_utils import requant_table
     mq, eq = requant_table(torch.tensor([0.0039]), torch.ones(1), torch.ones(1))
-    ref_q = orc.dyadic(ref_res, mq, eq, (0, 127))
+    ref_q = odyadic(orc, ref_res, mq, eq, (0, 127))
     md, ed = dev(m2), dev(e2)
     flags = torch.zeros(1, dtype=torch.int32, device='cuda')
     out_res = torch.zeros(ref_res.size, dtype=torch.uint16 if res_bits == 16 else torch.int32, device='cuda')
@@ -204,16 +210,16 @@ def test_residual_uint16_overflow_sets_flag(lib, orc):
     res = np.full((n, h, w, cout), 65000, np.uint16)
     keep['res'] = dev(res)
     m2 = np.full(cout, 1 << 30, np.int32)
-    e2 = np.full(cout, 31, np.int32)  # ratio 1/2
+    e2 = np.full(cout, 33 | (2 << 8), np.int32)  # ratio 1/2 (e=31 lifted by k=2)
     md, ed = dev(m2), dev(e2)
     flags = torch.zeros(1, dtype=torch.int32, device='cuda')
     out_res = torch.zeros(n * h * w * cout, dtype=torch.uint16, device='cuda')
     a.epilogue, a.m, a.e, a.flags = lib.EPI_RESIDUAL, md.data_ptr(), ed.data_ptr(), flags.data_ptr()
-    a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = keep['res'].data_ptr(), 16, 1 << 30, 30  # ratio 1
+    a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = keep['res'].data_ptr(), 16, 1 << 30, 33 | (3 << 8)  # ratio 1
     a.res_out, a.res_out_bits = out_res.data_ptr(), 16
     lib.call("hawq_conv2d", C.byref(a), stream())
     acc = orc.conv2d(x, wt, b, 1, 0)
-    expect_ovf = (np.maximum(orc.dyadic(acc, m2.astype(np.int64), e2) + 65000, 0) > 65535).any()
+    expect_ovf = (np.maximum(odyadic(orc, acc, m2, e2) + 65000, 0) > 65535).any()
     assert bool(flags.item() & 1) == bool(expect_ovf) and expect_ovf
 
 
@@ -246,7 +252,7 @@ def test_quantize_input_and_stem(lib, orc):
     b = rng.integers(-30000, 30000, 64).astype(np.int64)
     acc = orc.conv2d(q_ref, wt, b, 2, 3)
     m, e = rand_tables(rng, 64, 2e-3, 4e-2)
-    ref16 = np.maximum(orc.dyadic(acc, m, e, (-32768, 32767)), 0)
+    ref16 = np.maximum(odyadic(orc, acc, m, e, (-32768, 32767)), 0)
     wd, bd, md, ed = dev(pack_stem_weight(wt)), dev(b.astype(np.int32)), dev(m), dev(e)
     out16 = torch.zeros(n * ho * wo * 64, dtype=torch.uint16, device='cuda')
     out_acc = torch.zeros(n * ho * wo * 64, dtype=torch.int32, device='cuda')
@@ -265,7 +271,7 @@ def test_quantize_input_and_stem(lib, orc):
         lib.call("hawq_maxpool3s2_requant", out16.data_ptr(), n, ho, wo, 64, res.data_ptr(), qo.data_ptr(), bits,
                  int(mq[0]), int(eq[0]), lo, hi, stream())
         assert np.array_equal(res.cpu().numpy().astype(np.int64).reshape(n, h1, w1, 64).transpose(0, 3, 1, 2), pooled)
-        assert np.array_equal(unpack_q(qo, (n, h1, w1, 64), bits), orc.dyadic(pooled, mq, eq, (lo, hi)))
+        assert np.array_equal(unpack_q(qo, (n, h1, w1, 64), bits), odyadic(orc, pooled, mq, eq, (lo, hi)))
         q2 = torch.zeros_like(qo)
         lib.call("hawq_requant_residual", res.data_ptr(), 16, pooled.size, q2.data_ptr(), bits, int(mq[0]), int(eq[0]),
                  lo, hi, stream())
@@ -283,7 +289,7 @@ def test_avgpool_requant(lib, orc, res_bits):
     x[0, 1, 6, 6] = 4
     pooled = orc.avgpool_trunc(x)
     mq, eq = requant_table(torch.tensor([0.0038]), torch.ones(1), torch.ones(1))
-    ref = orc.dyadic(pooled, mq, eq, (-128, 127))
+    ref = odyadic(orc, pooled, mq, eq, (-128, 127))
     xin = dev(nhwc(x).astype(np.uint16 if res_bits == 16 else np.int32))
     out = torch.zeros(n * c, dtype=torch.int8, device='cuda')
     pd = torch.zeros(n * c, dtype=torch.int32, device='cuda')
