@@ -97,6 +97,33 @@ def cpu_baseline(model, x, gpu_logits, sample=16):
                        f"the reference path, {dt:.1f} s)", gpu_logits_bit_equal=parity)
 
 
+def write_per_op(path, ops, rows, batch):
+    """Per-launch table: measured ms vs the canonical byte/MAC model of the layers each launch covers."""
+    def model(name):
+        parts = []
+        base = name.split("+")[0]
+        if base in rows:
+            parts.append(rows[base])
+        if name.endswith("+identity"):
+            parts.append(rows[base.rsplit(".", 1)[0] + ".quant_identity_convbn"])
+        if name == "hawq_quantize_input":
+            parts.append(rows["quant_input"])
+        if name == "hawq_stem_conv7":
+            parts += [r for k, r in rows.items() if k.startswith("quant_init")]
+        if name == "hawq_avgpool_requant":
+            parts.append(rows["final_pool+quant_act_output"])
+        return (sum(r["act_bytes"] for r in parts) * batch + sum(r["weight_bytes"] for r in parts),
+                sum(r["macs"] for r in parts) * batch)
+    lines = ["| launch | ms | model MB | GB/s | % of 8 TB/s | GMAC | TOPS |", "|---|---|---|---|---|---|---|"]
+    for n, ms in ops:
+        b, mc = model(n)
+        lines.append(f"| {n} | {ms:.4f} | {b / 1e6:.1f} | {b / ms / 1e6:.0f} | {b / ms / 1e6 / 80:.1f} | {mc / 1e9:.2f} | "
+                     f"{2 * mc / ms / 1e9:.0f} |")
+    lines.append(f"\nsum of launches {sum(ms for _, ms in ops):.4f} ms")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +134,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / per-kernel table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", default=None, help="write a per-launch roofline table (markdown) to this file")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,6 +190,8 @@ def main():
             top = sorted(ops, key=lambda t: -t[1])[:8]
             out["roofline"]["eager_sum_ms"] = round(tot, 4)
             out["roofline"]["top_launches"] = [{"name": n, "ms": round(ms, 4)} for n, ms in top]
+            if args.per_op:
+                write_per_op(args.per_op, ops, rows, args.batch)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, x, eng.logits)
         else:

@@ -245,6 +245,35 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
     const int tc = wg % tiles_c, tm = wg / tiles_c;  // channel tiles of one pixel tile are adjacent
     const int m0 = tm * C::BM, c0 = tc * C::BN;
 
+    // Statically-typed kernels stage their epilogue through LDS so that every global access of
+    // the residual / output tensors is a full-line coalesced 16 B-per-lane access:
+    //   res tile [BM][BN] uint16 behind the operand staging buffers (filled asynchronously with
+    //   global_load_lds before the K loop, overwritten in place with the new residual),
+    //   q tile   [BM][BN] int8 aliased onto the staging buffers (free after the K loop).
+    // 16-B chunks are XOR-swizzled by the pixel row so that both the per-lane (one pixel, 16
+    // channels) and the row-contiguous access patterns are bank-conflict free.
+    constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
+    constexpr bool STAGED = BITS != 0 && (EPI == HAWQ_EPI_REQUANT || RES);
+    constexpr int RCPR = C::BN / 8;   // 16-B chunks per residual-tile row (uint16)
+    constexpr int QCPR = C::BN / 16;  // 16-B chunks per q-tile row (int8 positions)
+    char *res_tile = smem + C::LDS_BYTES;
+    char *q_tile = smem;
+    auto rsw = [](int row) { return row & (RCPR - 1); };
+    auto qsw = [](int row) { return QCPR >= 8 ? (row & (QCPR - 1)) : ((row >> 1) & (QCPR - 1)); };
+    if constexpr (STAGED && RES && !DUAL) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int i = 0; i < C::BM * RCPR / 256; ++i) {
+            const int base = (i * 4 + wave) * 64;
+            const int idx = base + lane;
+            const int row = idx / RCPR, j = idx % RCPR;
+            const int grow = (m0 + row < p.M) ? m0 + row : m0;
+            const char *src = (const char *)p.res_in + ((size_t)grow * p.Cout + c0) * 2 + ((j ^ rsw(row)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(res_tile + base * 16), 16, 0, 0);
+        }
+    }
+
     v16i acc[C::CT][C::PT];
 #pragma unroll
     for (int c = 0; c < C::CT; ++c)
@@ -303,11 +332,20 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
                             (float)(acc[c][q][r] + p.bias[ch + r]) * p.fscale[ch + r];
             }
         } else {
-            constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
             // residual inputs of this channel tile are fetched first so that their latency overlaps
             // the table loads and the requant arithmetic
             v4i rin[C::PT][(RES && !DUAL) ? 4 : 1];
-            if constexpr (RES && !DUAL) {
+            const int lrow0 = wave_m * (C::PT * 32) + l31;                     // tile-local pixel row of q = 0
+            const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;           // tile-local first channel
+            if constexpr (STAGED && RES && !DUAL) {
+#pragma unroll
+                for (int q = 0; q < C::PT; ++q) {
+                    const int row = lrow0 + q * 32;
+                    const char *base = res_tile + row * (RCPR * 16);
+                    rin[q][0] = *reinterpret_cast<const v4i *>(base + ((((lch >> 3)) ^ rsw(row)) << 4));
+                    rin[q][1] = *reinterpret_cast<const v4i *>(base + ((((lch >> 3) + 1) ^ rsw(row)) << 4));
+                }
+            } else if constexpr (RES && !DUAL) {
 #pragma unroll
                 for (int q = 0; q < C::PT; ++q) {
                     const size_t elem = (size_t)(pix[q] < p.M ? pix[q] : 0) * p.Cout + ch;
@@ -364,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
                         if constexpr (DUAL) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) idin[j] = acc2[c][q][4 * g + j] + bb2[j];
-                        } else if (p.res_in_bits == 16) {
+                        } else if (STAGED || p.res_in_bits == 16) {
                             const int w0 = rin[q][g >> 1][(g & 1) * 2], w1 = rin[q][g >> 1][(g & 1) * 2 + 1];
                             idin[0] = w0 & 0xffff, idin[1] = (int)((unsigned)w0 >> 16);
                             idin[2] = w1 & 0xffff, idin[3] = (int)((unsigned)w1 >> 16);
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) ovf |= o[j] > 65535;
-                        if (p.res_out_bits == 16) {
+                        if (STAGED || p.res_out_bits == 16) {
                             rpack[q][RES ? 2 * g : 0] = min(o[0], 65535) | (min(o[1], 65535) << 16);
                             rpack[q][RES ? 2 * g + 1 : 0] = min(o[2], 65535) | (min(o[3], 65535) << 16);
                         } else {
@@ -411,40 +449,96 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
                     }
                 }
             }
+            if constexpr (STAGED) {
 #pragma unroll
-            for (int q = 0; q < C::PT; ++q) {
-                if (pix[q] >= p.M) continue;
-                const size_t elem = (size_t)pix[q] * p.Cout + ch;
-                if constexpr (RES) {
-                    if (p.res_out) {
-                        if (p.res_out_bits == 16) {
-                            v4i *dst = reinterpret_cast<v4i *>((uint16_t *)p.res_out + elem);
-                            v4i a = {rpack[q][0], rpack[q][1], rpack[q][2], rpack[q][3]};
-                            v4i b = {rpack[q][4], rpack[q][5], rpack[q][6], rpack[q][7]};
-                            dst[0] = a;
-                            dst[1] = b;
-                        } else {
+                for (int q = 0; q < C::PT; ++q) {
+                    const int row = lrow0 + q * 32;
+                    if constexpr (RES) {
+                        char *base = res_tile + row * (RCPR * 16);
+                        v4i a = {rpack[q][0], rpack[q][1], rpack[q][2], rpack[q][3]};
+                        v4i b = {rpack[q][4], rpack[q][5], rpack[q][6], rpack[q][7]};
+                        *reinterpret_cast<v4i *>(base + (((lch >> 3) ^ rsw(row)) << 4)) = a;
+                        *reinterpret_cast<v4i *>(base + ((((lch >> 3) + 1) ^ rsw(row)) << 4)) = b;
+                    }
+                    char *qb = q_tile + row * (QCPR * 16) + (((lch >> 4) ^ qsw(row)) << 4);
+                    if (p.out_bits == 8) {
+                        v4i w = {qpack[q][0], qpack[q][1], qpack[q][2], qpack[q][3]};
+                        *reinterpret_cast<v4i *>(qb) = w;
+                    } else {
+                        v2i w = {qpack[q][0], qpack[q][1]};
+                        *reinterpret_cast<v2i *>(qb) = w;
+                    }
+                }
+            } else {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                v4i w = {rpack[q][4 * i], rpack[q][4 * i + 1], rpack[q][4 * i + 2],
-                                         rpack[q][4 * i + 3]};
-                                reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[i] = w;
+                for (int q = 0; q < C::PT; ++q) {
+                    if (pix[q] >= p.M) continue;
+                    const size_t elem = (size_t)pix[q] * p.Cout + ch;
+                    if constexpr (RES) {
+                        if (p.res_out) {
+                            if (p.res_out_bits == 16) {
+                                v4i *dst = reinterpret_cast<v4i *>((uint16_t *)p.res_out + elem);
+                                v4i a = {rpack[q][0], rpack[q][1], rpack[q][2], rpack[q][3]};
+                                v4i b = {rpack[q][4], rpack[q][5], rpack[q][6], rpack[q][7]};
+                                dst[0] = a;
+                                dst[1] = b;
+                            } else {
+    #pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    v4i w = {rpack[q][4 * i], rpack[q][4 * i + 1], rpack[q][4 * i + 2],
+                                             rpack[q][4 * i + 3]};
+                                    reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[i] = w;
+                                }
                             }
                         }
                     }
-                }
-                if (!RES || p.out_q) {
-                    if (p.out_bits == 8) {
-                        v4i w = {qpack[q][0], qpack[q][1], qpack[q][2], qpack[q][3]};
-                        *reinterpret_cast<v4i *>((char *)p.out_q + elem) = w;
-                    } else {
-                        v2i w = {qpack[q][0], qpack[q][1]};
-                        *reinterpret_cast<v2i *>((char *)p.out_q + (elem >> 1)) = w;
+                    if (!RES || p.out_q) {
+                        if (p.out_bits == 8) {
+                            v4i w = {qpack[q][0], qpack[q][1], qpack[q][2], qpack[q][3]};
+                            *reinterpret_cast<v4i *>((char *)p.out_q + elem) = w;
+                        } else {
+                            v2i w = {qpack[q][0], qpack[q][1]};
+                            *reinterpret_cast<v2i *>((char *)p.out_q + (elem >> 1)) = w;
+                        }
                     }
                 }
             }
             if constexpr (RES) {
-                if (ovf && p.res_out && p.res_out_bits == 16) atomicOr(p.flags, 1);
+                if (ovf && p.res_out && (STAGED || p.res_out_bits == 16)) atomicOr(p.flags, 1);
+            }
+        }
+    }
+    if constexpr (STAGED) {
+        __syncthreads();
+        const int t = threadIdx.x;
+        if constexpr (RES) {
+            if (p.res_out) {
+#pragma unroll
+                for (int i = 0; i < C::BM * RCPR / 256; ++i) {
+                    const int idx = t + 256 * i;
+                    const int row = idx / RCPR, j = idx % RCPR;
+                    if (m0 + row < p.M) {
+                        const v4i v = *reinterpret_cast<const v4i *>(res_tile + idx * 16);
+                        char *dst = (char *)p.res_out + ((size_t)(m0 + row) * p.Cout + c0) * 2 + ((j ^ rsw(row)) << 4);
+                        *reinterpret_cast<v4i *>(dst) = v;
+                    }
+                }
+            }
+        }
+        if (!RES || p.out_q) {
+#pragma unroll
+            for (int i = 0; i < (C::BM * QCPR + 255) / 256; ++i) {
+                const int idx = t + 256 * i;
+                const int row = idx / QCPR, j = idx % QCPR;
+                if (idx < C::BM * QCPR && m0 + row < p.M) {
+                    const size_t e0 = (size_t)(m0 + row) * p.Cout + c0 + ((j ^ qsw(row)) << 4);
+                    if (p.out_bits == 8) {
+                        *reinterpret_cast<v4i *>((char *)p.out_q + e0) = *reinterpret_cast<const v4i *>(q_tile + idx * 16);
+                    } else {
+                        *reinterpret_cast<v2i *>((char *)p.out_q + (e0 >> 1)) =
+                            *reinterpret_cast<const v2i *>(q_tile + idx * 16);
+                    }
+                }
             }
         }
     }
@@ -479,6 +573,22 @@ struct TileInfo {
         }                                                                                                      \
     }
 const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0), TILE_ENTRY(T1), TILE_ENTRY(T2), TILE_ENTRY(T3)};
+
+// kernels whose staged epilogue needs more than the default 64 KiB of dynamic LDS
+bool raise_lds_limits() {
+    bool ok = true;
+    for (const TileInfo &ti : kTiles) {
+        const int lds = ti.lds + ti.BM * ti.BN * 2;
+        if (lds <= 64 * 1024) continue;
+        for (int v = 1; v < 3; ++v)
+            ok &= hipFuncSetAttribute((const void *)ti.single[2][v], hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
+                  hipSuccess;
+        for (int v = 1; v < 5; ++v)
+            ok &= hipFuncSetAttribute((const void *)ti.dual[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
+                  hipSuccess;
+    }
+    return ok;
+}
 
 int pick_tile(int M, int Cout, bool dual) {
     // Enough workgroups to fill 256 CUs a few times over, the largest tile that allows it.
@@ -587,15 +697,24 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (p.Cout % kTiles[tile].BN != 0) tile = 2;
     const TileInfo &ti = kTiles[tile];
     const int grid = ((p.M + ti.BM - 1) / ti.BM) * (p.Cout / ti.BN);
-    auto variant = [](int ab, int wb) { return ab == 8 && wb == 8 ? 1 : (ab == 4 && wb == 4 ? 2 : 0); };
+    // 32-bit residual tensors use the generic (run-time bit-width, direct epilogue) kernels
+    const bool wide_res = a->epilogue == HAWQ_EPI_RESIDUAL &&
+                          ((!dual && a->res_in_bits == 32) || (a->res_out && a->res_out_bits == 32));
+    auto variant = [&](int ab, int wb) { return wide_res ? 0 : (ab == 8 && wb == 8 ? 1 : (ab == 4 && wb == 4 ? 2 : 0)); };
     KernelFn fn;
+    int lds = ti.lds;
     if (dual) {
         const int v1 = variant(p.in_bits, p.w_bits), v2 = variant(p.in2_bits, p.w2_bits);
         fn = (v1 == 0 || v2 == 0) ? ti.dual[0] : ti.dual[v1 == v2 ? v1 : (v1 == 1 ? 3 : 4)];
+        if (v1 != 0 && v2 != 0) lds += ti.BM * ti.BN * 2;
     } else {
-        fn = ti.single[slot][variant(p.in_bits, p.w_bits)];
+        const int v = variant(p.in_bits, p.w_bits);
+        fn = ti.single[slot][v];
+        if (v != 0 && slot == 2) lds += ti.BM * ti.BN * 2;
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), ti.lds, (hipStream_t)stream, p);
+    static const bool attrs_ok = raise_lds_limits();  // once per process; never inside a capture
+    HAWQ_REQUIRE(attrs_ok, "hawq_conv2d: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }
