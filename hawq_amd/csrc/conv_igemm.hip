@@ -211,7 +211,7 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
     }
 }
 
-// BITS: 0 = decide at run time (generic fallback, costs registers), else (a_bits << 4) | w_bits.
+// BITS: 0 = decide at run time (generic kernels), else (a_bits << 4) | w_bits.
 template <class C, int BITS>
 __device__ __forceinline__ void run_segment(v16i (&acc)[C::CT][C::PT], const uint8_t *in, const uint8_t *wgt,
                                             int a_bits, int w_bits, int H, int W, int Cin, int KH, int KW,
@@ -229,6 +229,291 @@ __device__ __forceinline__ void run_segment(v16i (&acc)[C::CT][C::PT], const uin
 
 __device__ __forceinline__ v4i ld4(const int32_t *p) { return *reinterpret_cast<const v4i *>(p); }
 
+// 4 ints already clamped to the int8 range -> one dword (byte 0 = first): 2x v_cvt_pk_i16_i32 + v_perm
+__device__ __forceinline__ int pack4_fast(int a, int b, int c, int d) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 lo = __builtin_amdgcn_cvt_pk_i16(a, b), hi = __builtin_amdgcn_cvt_pk_i16(c, d);
+    return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
+}
+// two non-negative ints -> saturating uint16 pair (v_cvt_pk_u16_u32)
+__device__ __forceinline__ int pack2_u16_sat(int a, int b) {
+    typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_cvt_pk_u16((unsigned)a, (unsigned)b);
+    return __builtin_bit_cast(int, r);
+}
+
+// =============================================================== exact general epilogue (BITS == 0)
+// Direct per-lane global accesses, dyadic_rne everywhere: any e in [1,62], any pre-shift, ties
+// handled, 16- or 32-bit residuals, run-time operand widths.  Slow but always right.
+template <class C, int EPI, bool DUAL>
+__device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::CT][C::PT],
+                                                 v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) {
+        const int ch = c0 + wave_c * (C::CT * 32) + c * 32 + h * 16;
+#pragma unroll
+        for (int q = 0; q < C::PT; ++q) {
+            const int pix = m0 + wave_m * (C::PT * 32) + q * 32 + l31;
+            if (pix >= p.M) continue;
+            const size_t elem = (size_t)pix * p.Cout + ch;
+            bool ovf = false;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4i b4 = ld4(p.bias + ch + 4 * g);
+                const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                int v[4], qv[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[c][q][4 * g + j] + bb[j];
+                if constexpr (EPI == HAWQ_EPI_RAW) {
+                    v4i w = {v[0], v[1], v[2], v[3]};
+                    reinterpret_cast<v4i *>(p.out_acc + elem)[g] = w;
+                } else if constexpr (EPI == HAWQ_EPI_DEQUANT) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ch + 4 * g + j < p.n_valid)
+                            p.out_f32[(size_t)pix * p.ldo + ch + 4 * g + j] = (float)v[j] * p.fscale[ch + 4 * g + j];
+                } else {
+                    const v4i m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
+                    const int mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+                    if constexpr (EPI == HAWQ_EPI_REQUANT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            qv[j] = clampi(dyadic_rne(p.relu ? max(v[j], 0) : v[j], mm[j], ee[j]), p.q_lo, p.q_hi);
+                    } else {
+                        int idv[4];
+                        if constexpr (DUAL) {
+                            const v4i b2 = ld4(p.bias2 + ch + 4 * g), mi = ld4(p.m_id + ch + 4 * g),
+                                      ei = ld4(p.e_id + ch + 4 * g);
+                            const int bb2[4] = {b2.x, b2.y, b2.z, b2.w}, m1[4] = {mi.x, mi.y, mi.z, mi.w},
+                                      e1[4] = {ei.x, ei.y, ei.z, ei.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) idv[j] = dyadic_rne(acc2[DUAL ? c : 0][DUAL ? q : 0][4 * g + j] + bb2[j], m1[j], e1[j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int r = p.res_in_bits == 16 ? (int)((const uint16_t *)p.res_in)[elem + 4 * g + j]
+                                                                  : ((const int32_t *)p.res_in)[elem + 4 * g + j];
+                                idv[j] = dyadic_rne(r, p.m_id_s, p.e_id_s);
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o[j] = max(dyadic_rne(v[j], mm[j], ee[j]) + idv[j], 0);  // no clamp: quant_utils.py:456
+                            qv[j] = clampi(dyadic_rne(o[j], p.mq, p.eq), p.q_lo, p.q_hi);
+                            ovf |= o[j] > 65535;
+                        }
+                        if (p.res_out) {
+                            if (p.res_out_bits == 16) {
+                                v2i w = {min(o[0], 65535) | (min(o[1], 65535) << 16), min(o[2], 65535) | (min(o[3], 65535) << 16)};
+                                reinterpret_cast<v2i *>((uint16_t *)p.res_out + elem)[g] = w;
+                            } else {
+                                v4i w = {o[0], o[1], o[2], o[3]};
+                                reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[g] = w;
+                            }
+                        }
+                    }
+                    if (EPI == HAWQ_EPI_REQUANT || p.out_q) {
+                        if (p.out_bits == 8) {
+                            reinterpret_cast<uint32_t *>((char *)p.out_q + elem)[g] = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+                        } else {  // hawq4: byte k of an 8-channel group = c_k | c_{k+4} << 4
+                            uint8_t *dst = (uint8_t *)p.out_q + (elem >> 1) + (g >> 1) * 4;
+                            if (g & 1) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) dst[j] = (uint8_t)((dst[j] & 0x0f) | (qv[j] << 4));
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) dst[j] = (uint8_t)(qv[j] & 0x0f);
+                            }
+                        }
+                    }
+                }
+            }
+            if (EPI == HAWQ_EPI_RESIDUAL && ovf && p.res_out && p.res_out_bits == 16) atomicOr(p.flags, 1);
+        }
+    }
+}
+
+// =============================================================== fast epilogue (BITS != 0)
+// Host-proved tables (see dyadic_nt), uint16 residuals, everything staged through LDS so that
+// each global access of the residual / output tensors is a full-line coalesced 16 B-per-lane access:
+//   res tile [BM][BN] uint16 behind the operand staging buffers (filled asynchronously with
+//   global_load_lds before the K loop, overwritten in place with the new residual),
+//   q tile   [BM][BN] int8 positions, aliased onto the staging buffers (free after the K loop).
+// 16-B chunks are XOR-swizzled by the pixel row so that both the per-lane (one pixel, 16 channels)
+// and the row-contiguous access patterns are bank-conflict free.
+template <class C>
+struct Stage {
+    static constexpr int RCPR = C::BN / 8;   // 16-B chunks per residual-tile row (uint16)
+    static constexpr int QCPR = C::BN / 16;  // 16-B chunks per q-tile row
+    __device__ static __forceinline__ int rsw(int row) { return row & (RCPR - 1); }
+    __device__ static __forceinline__ int qsw(int row) {
+        return QCPR >= 8 ? (row & (QCPR - 1)) : ((row >> 1) & (QCPR - 1));
+    }
+};
+
+template <class C>
+__device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0, char *res_tile) {
+    using S = Stage<C>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < C::BM * S::RCPR / 256; ++i) {
+        const int base = (i * 4 + wave) * 64;
+        const int idx = base + lane;
+        const int row = idx / S::RCPR, j = idx % S::RCPR;
+        const int grow = (m0 + row < p.M) ? m0 + row : m0;
+        const char *src = (const char *)p.res_in + ((size_t)grow * p.Cout + c0) * 2 + ((j ^ S::rsw(row)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(res_tile + base * 16), 16, 0, 0);
+    }
+}
+
+template <class C, int EPI, bool DUAL>
+__device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
+                                              v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
+                                              char *q_tile, char *res_tile) {
+    using S = Stage<C>;
+    constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int lrow0 = wave_m * (C::PT * 32) + l31;  // tile-local pixel row of pixel tile 0
+    const int relu_floor = p.relu ? 0 : (int)0x80000000;
+    const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    const int kid = p.e_id_s >> 8;  // pre-shift of the scalar identity table, applied while unpacking
+    int omax = 0;
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) {
+        const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;  // tile-local first channel of this lane
+        const int ch = c0 + lch;
+        v4i rin[C::PT][2];
+        if constexpr (RES && !DUAL) {
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q) {
+                const int row = lrow0 + q * 32;
+                const char *base = res_tile + row * (S::RCPR * 16);
+                rin[q][0] = *reinterpret_cast<const v4i *>(base + (((lch >> 3) ^ S::rsw(row)) << 4));
+                rin[q][1] = *reinterpret_cast<const v4i *>(base + ((((lch >> 3) + 1) ^ S::rsw(row)) << 4));
+            }
+        }
+        // Two accumulator sets (DUAL) leave no room to keep every pixel tile's packed outputs live:
+        // walk the pixel tiles one at a time there (the channel constants are re-read from L1).
+        constexpr int QPASS = DUAL ? C::PT : 1, QPER = C::PT / QPASS;
+#pragma unroll
+        for (int qp = 0; qp < QPASS; ++qp) {
+        int qpack[QPER][4];            // 16 x int8, or 2 dwords of hawq4 in [0..1]
+        int rpack[QPER][RES ? 8 : 1];  // 16 x uint16
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4i b4 = ld4(p.bias + ch + 4 * g), m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
+            const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            const DyNt dm[4] = {dynt_prepare(m4.x, e4.x), dynt_prepare(m4.y, e4.y), dynt_prepare(m4.z, e4.z),
+                                dynt_prepare(m4.w, e4.w)};
+            int bb2[4] = {0, 0, 0, 0};
+            DyNt di[4] = {dids, dids, dids, dids};
+            if constexpr (DUAL) {
+                const v4i b2 = ld4(p.bias2 + ch + 4 * g), mi = ld4(p.m_id + ch + 4 * g), ei = ld4(p.e_id + ch + 4 * g);
+                bb2[0] = b2.x, bb2[1] = b2.y, bb2[2] = b2.z, bb2[3] = b2.w;
+                di[0] = dynt_prepare(mi.x, ei.x), di[1] = dynt_prepare(mi.y, ei.y);
+                di[2] = dynt_prepare(mi.z, ei.z), di[3] = dynt_prepare(mi.w, ei.w);
+            }
+#pragma unroll
+            for (int qq = 0; qq < QPER; ++qq) {
+                const int q = qp * QPER + qq;
+                int qv[4];
+                if constexpr (!RES) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        qv[j] = dyadic_nt(max(acc[c][q][4 * g + j] + bb[j], relu_floor), dm[j]);
+                } else {
+                    int idin[4], o[4];
+                    if constexpr (DUAL) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) idin[j] = acc2[DUAL ? c : 0][DUAL ? q : 0][4 * g + j] + bb2[j];
+                    } else {
+                        const unsigned w0 = (unsigned)rin[q][g >> 1][(g & 1) * 2], w1 = (unsigned)rin[q][g >> 1][(g & 1) * 2 + 1];
+                        idin[0] = (int)((w0 & 0xffffu) << kid), idin[1] = (int)((w0 >> 16) << kid);
+                        idin[2] = (int)((w1 & 0xffffu) << kid), idin[3] = (int)((w1 >> 16) << kid);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int a = dyadic_nt(acc[c][q][4 * g + j] + bb[j], dm[j]);
+                        const int b = dyadic_nt(idin[j], di[j]);
+                        o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
+                        omax = max(omax, o[j]);
+                        qv[j] = dyadic_nt(o[j], dq);
+                    }
+                    rpack[qq][RES ? 2 * g : 0] = pack2_u16_sat(o[0], o[1]);
+                    rpack[qq][RES ? 2 * g + 1 : 0] = pack2_u16_sat(o[2], o[3]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[j] = min(max(qv[j], p.q_lo), p.q_hi);
+                const int w = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                if (p.out_bits == 8) {
+                    qpack[qq][g] = w;
+                } else if (g & 1) {  // hawq4: low nibbles = channels 0-3 of the 8-group, high = 4-7
+                    qpack[qq][g >> 1] |= w << 4;
+                } else {
+                    qpack[qq][g >> 1] = w;
+                }
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < QPER; ++qq) {
+            const int q = qp * QPER + qq;
+            const int row = lrow0 + q * 32;
+            if constexpr (RES) {
+                char *base = res_tile + row * (S::RCPR * 16);
+                v4i a = {rpack[qq][0], rpack[qq][1], rpack[qq][2], rpack[qq][3]};
+                v4i b = {rpack[qq][4], rpack[qq][5], rpack[qq][6], rpack[qq][7]};
+                *reinterpret_cast<v4i *>(base + (((lch >> 3) ^ S::rsw(row)) << 4)) = a;
+                *reinterpret_cast<v4i *>(base + ((((lch >> 3) + 1) ^ S::rsw(row)) << 4)) = b;
+            }
+            char *qb = q_tile + row * (S::QCPR * 16) + (((lch >> 4) ^ S::qsw(row)) << 4);
+            if (p.out_bits == 8) {
+                v4i w = {qpack[qq][0], qpack[qq][1], qpack[qq][2], qpack[qq][3]};
+                *reinterpret_cast<v4i *>(qb) = w;
+            } else {
+                v2i w = {qpack[qq][0], qpack[qq][1]};
+                *reinterpret_cast<v2i *>(qb) = w;
+            }
+        }
+        }  // qp
+    }
+    if (RES && omax > 65535 && p.res_out) atomicOr(p.flags, 1);  // rows beyond M never reach memory but may flag: harmless
+    __syncthreads();
+    const int t = threadIdx.x;
+    if constexpr (RES) {
+        if (p.res_out) {
+#pragma unroll
+            for (int i = 0; i < C::BM * S::RCPR / 256; ++i) {
+                const int idx = t + 256 * i;
+                const int row = idx / S::RCPR, j = idx % S::RCPR;
+                if (m0 + row < p.M) {
+                    char *dst = (char *)p.res_out + ((size_t)(m0 + row) * p.Cout + c0) * 2 + ((j ^ S::rsw(row)) << 4);
+                    *reinterpret_cast<v4i *>(dst) = *reinterpret_cast<const v4i *>(res_tile + idx * 16);
+                }
+            }
+        }
+    }
+    if (!RES || p.out_q) {
+#pragma unroll
+        for (int i = 0; i < (C::BM * S::QCPR + 255) / 256; ++i) {
+            const int idx = t + 256 * i;
+            const int row = idx / S::QCPR, j = idx % S::QCPR;
+            if (idx < C::BM * S::QCPR && m0 + row < p.M) {
+                const size_t e0 = (size_t)(m0 + row) * p.Cout + c0 + ((j ^ S::qsw(row)) << 4);
+                if (p.out_bits == 8)
+                    *reinterpret_cast<v4i *>((char *)p.out_q + e0) = *reinterpret_cast<const v4i *>(q_tile + idx * 16);
+                else
+                    *reinterpret_cast<v2i *>((char *)p.out_q + (e0 >> 1)) = *reinterpret_cast<const v2i *>(q_tile + idx * 16);
+            }
+        }
+    }
+}
+
 template <class C, int EPI, bool DUAL, int BITS, int BITS2>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,35 +529,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
     }
     const int tc = wg % tiles_c, tm = wg / tiles_c;  // channel tiles of one pixel tile are adjacent
     const int m0 = tm * C::BM, c0 = tc * C::BN;
-
-    // Statically-typed kernels stage their epilogue through LDS so that every global access of
-    // the residual / output tensors is a full-line coalesced 16 B-per-lane access:
-    //   res tile [BM][BN] uint16 behind the operand staging buffers (filled asynchronously with
-    //   global_load_lds before the K loop, overwritten in place with the new residual),
-    //   q tile   [BM][BN] int8 aliased onto the staging buffers (free after the K loop).
-    // 16-B chunks are XOR-swizzled by the pixel row so that both the per-lane (one pixel, 16
-    // channels) and the row-contiguous access patterns are bank-conflict free.
-    constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
-    constexpr bool STAGED = BITS != 0 && (EPI == HAWQ_EPI_REQUANT || RES);
-    constexpr int RCPR = C::BN / 8;   // 16-B chunks per residual-tile row (uint16)
-    constexpr int QCPR = C::BN / 16;  // 16-B chunks per q-tile row (int8 positions)
+    constexpr bool FAST = BITS != 0 && (EPI == HAWQ_EPI_REQUANT || EPI == HAWQ_EPI_RESIDUAL);
     char *res_tile = smem + C::LDS_BYTES;
-    char *q_tile = smem;
-    auto rsw = [](int row) { return row & (RCPR - 1); };
-    auto qsw = [](int row) { return QCPR >= 8 ? (row & (QCPR - 1)) : ((row >> 1) & (QCPR - 1)); };
-    if constexpr (STAGED && RES && !DUAL) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-        for (int i = 0; i < C::BM * RCPR / 256; ++i) {
-            const int base = (i * 4 + wave) * 64;
-            const int idx = base + lane;
-            const int row = idx / RCPR, j = idx % RCPR;
-            const int grow = (m0 + row < p.M) ? m0 + row : m0;
-            const char *src = (const char *)p.res_in + ((size_t)grow * p.Cout + c0) * 2 + ((j ^ rsw(row)) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(res_tile + base * 16), 16, 0, 0);
-        }
-    }
+    if constexpr (FAST && EPI == HAWQ_EPI_RESIDUAL && !DUAL) prefetch_residual<C>(p, m0, c0, res_tile);
 
     v16i acc[C::CT][C::PT];
 #pragma unroll
@@ -294,254 +553,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
         run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2, 0,
                               p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
     }
-
-    // ---------------------------------------------------------------- epilogue
-    // Lane (l31, h) owns pixel l31 of each pixel tile and channels ch..ch+15 of each channel tile.
-    // Channels are processed in 4 groups of 4 to keep the per-channel constants in few registers.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
-    const int l31 = lane & 31, h = lane >> 5;
-    int pix[C::PT];
-#pragma unroll
-    for (int q = 0; q < C::PT; ++q) pix[q] = m0 + wave_m * (C::PT * 32) + q * 32 + l31;
-
-#pragma unroll
-    for (int c = 0; c < C::CT; ++c) {
-        const int ch = c0 + wave_c * (C::CT * 32) + c * 32 + h * 16;  // first of this lane's 16 channels
-        if constexpr (EPI == HAWQ_EPI_RAW) {
-#pragma unroll
-            for (int q = 0; q < C::PT; ++q) {
-                if (pix[q] >= p.M) continue;
-                const size_t elem = (size_t)pix[q] * p.Cout + ch;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const v4i b = ld4(p.bias + ch + 4 * g);
-                    v4i w = {acc[c][q][4 * g] + b.x, acc[c][q][4 * g + 1] + b.y, acc[c][q][4 * g + 2] + b.z,
-                             acc[c][q][4 * g + 3] + b.w};
-                    reinterpret_cast<v4i *>(p.out_acc + elem)[g] = w;
-                }
-            }
-        } else if constexpr (EPI == HAWQ_EPI_DEQUANT) {
-#pragma unroll
-            for (int q = 0; q < C::PT; ++q) {
-                if (pix[q] >= p.M) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (ch + r < p.n_valid)
-                        p.out_f32[(size_t)pix[q] * p.ldo + ch + r] =
-                            (float)(acc[c][q][r] + p.bias[ch + r]) * p.fscale[ch + r];
-            }
-        } else {
-            // residual inputs of this channel tile are fetched first so that their latency overlaps
-            // the table loads and the requant arithmetic
-            v4i rin[C::PT][(RES && !DUAL) ? 4 : 1];
-            const int lrow0 = wave_m * (C::PT * 32) + l31;                     // tile-local pixel row of q = 0
-            const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;           // tile-local first channel
-            if constexpr (STAGED && RES && !DUAL) {
-#pragma unroll
-                for (int q = 0; q < C::PT; ++q) {
-                    const int row = lrow0 + q * 32;
-                    const char *base = res_tile + row * (RCPR * 16);
-                    rin[q][0] = *reinterpret_cast<const v4i *>(base + ((((lch >> 3)) ^ rsw(row)) << 4));
-                    rin[q][1] = *reinterpret_cast<const v4i *>(base + ((((lch >> 3) + 1) ^ rsw(row)) << 4));
-                }
-            } else if constexpr (RES && !DUAL) {
-#pragma unroll
-                for (int q = 0; q < C::PT; ++q) {
-                    const size_t elem = (size_t)(pix[q] < p.M ? pix[q] : 0) * p.Cout + ch;
-                    if (p.res_in_bits == 16) {
-                        const v4i *src = reinterpret_cast<const v4i *>((const uint16_t *)p.res_in + elem);
-                        rin[q][0] = src[0];
-                        rin[q][1] = src[1];
-                    } else {
-                        const v4i *src = reinterpret_cast<const v4i *>((const int32_t *)p.res_in + elem);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rin[q][i] = src[i];
-                    }
-                }
-            }
-            int qpack[C::PT][4];             // 16 x int8, or 2 dwords of hawq4 in [0..1]
-            int rpack[C::PT][RES ? 16 : 1];  // uint16 pairs in [0..7] or 16 x int32
-            bool ovf = false;
-            const DyCh dids = dy_prepare(p.m_id_s, p.e_id_s), dq = dy_prepare(p.mq, p.eq);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const v4i b4 = ld4(p.bias + ch + 4 * g), m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
-                const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
-                const int mraw[4] = {m4.x, m4.y, m4.z, m4.w}, eraw[4] = {e4.x, e4.y, e4.z, e4.w};
-                DyCh dm[4], di[4];
-                int bb2[4] = {0, 0, 0, 0}, m2raw[4] = {0, 0, 0, 0}, e2raw[4] = {33, 33, 33, 33};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dm[j] = dy_prepare(mraw[j], eraw[j]);
-                if constexpr (DUAL) {
-                    const v4i b2 = ld4(p.bias2 + ch + 4 * g), mi = ld4(p.m_id + ch + 4 * g),
-                              ei = ld4(p.e_id + ch + 4 * g);
-                    bb2[0] = b2.x, bb2[1] = b2.y, bb2[2] = b2.z, bb2[3] = b2.w;
-                    m2raw[0] = mi.x, m2raw[1] = mi.y, m2raw[2] = mi.z, m2raw[3] = mi.w;
-                    e2raw[0] = ei.x, e2raw[1] = ei.y, e2raw[2] = ei.z, e2raw[3] = ei.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) di[j] = DUAL ? dy_prepare(m2raw[j], e2raw[j]) : dids;
-#pragma unroll
-                for (int q = 0; q < C::PT; ++q) {
-                    int v[4], idin[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0}, qv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[c][q][4 * g + j] + bb[j];
-                    unsigned zmin = 0xffffffffu;
-                    if constexpr (!RES) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (p.relu) v[j] = max(v[j], 0);
-                            qv[j] = dyadic_fast(v[j], dm[j], zmin);
-                        }
-                        if (__builtin_amdgcn_ballot_w64(zmin == 0)) {  // an exact tie in this wave: redo exactly
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) qv[j] = dyadic_rne(v[j], mraw[j], eraw[j]);
-                        }
-                    } else {
-                        if constexpr (DUAL) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) idin[j] = acc2[c][q][4 * g + j] + bb2[j];
-                        } else if (STAGED || p.res_in_bits == 16) {
-                            const int w0 = rin[q][g >> 1][(g & 1) * 2], w1 = rin[q][g >> 1][(g & 1) * 2 + 1];
-                            idin[0] = w0 & 0xffff, idin[1] = (int)((unsigned)w0 >> 16);
-                            idin[2] = w1 & 0xffff, idin[3] = (int)((unsigned)w1 >> 16);
-                        } else {
-                            const v4i w = rin[q][(RES && !DUAL) ? g : 0];
-                            idin[0] = w.x, idin[1] = w.y, idin[2] = w.z, idin[3] = w.w;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int a = dyadic_fast(v[j], dm[j], zmin);
-                            const int b = dyadic_fast(idin[j], di[j], zmin);
-                            o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
-                            qv[j] = dyadic_fast(o[j], dq, zmin);
-                        }
-                        if (__builtin_amdgcn_ballot_w64(zmin == 0)) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int a = dyadic_rne(v[j], mraw[j], eraw[j]);
-                                const int b = DUAL ? dyadic_rne(idin[j], m2raw[j], e2raw[j])
-                                                   : dyadic_rne(idin[j], p.m_id_s, p.e_id_s);
-                                o[j] = max(a + b, 0);
-                                qv[j] = dyadic_rne(o[j], p.mq, p.eq);
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) ovf |= o[j] > 65535;
-                        if (STAGED || p.res_out_bits == 16) {
-                            rpack[q][RES ? 2 * g : 0] = min(o[0], 65535) | (min(o[1], 65535) << 16);
-                            rpack[q][RES ? 2 * g + 1 : 0] = min(o[2], 65535) | (min(o[3], 65535) << 16);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) rpack[q][RES ? 4 * g + j : 0] = o[j];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) qv[j] = clampi(qv[j], p.q_lo, p.q_hi);
-                    const int w = (int)pack4_i8(qv[0], qv[1], qv[2], qv[3]);
-                    if (p.out_bits == 8) {
-                        qpack[q][g] = w;
-                    } else if (g & 1) {  // hawq4: low nibbles = channels 0-3 of the 8-group, high = 4-7
-                        qpack[q][g >> 1] |= w << 4;
-                    } else {
-                        qpack[q][g >> 1] = w;
-                    }
-                }
-            }
-            if constexpr (STAGED) {
-#pragma unroll
-                for (int q = 0; q < C::PT; ++q) {
-                    const int row = lrow0 + q * 32;
-                    if constexpr (RES) {
-                        char *base = res_tile + row * (RCPR * 16);
-                        v4i a = {rpack[q][0], rpack[q][1], rpack[q][2], rpack[q][3]};
-                        v4i b = {rpack[q][4], rpack[q][5], rpack[q][6], rpack[q][7]};
-                        *reinterpret_cast<v4i *>(base + (((lch >> 3) ^ rsw(row)) << 4)) = a;
-                        *reinterpret_cast<v4i *>(base + ((((lch >> 3) + 1) ^ rsw(row)) << 4)) = b;
-                    }
-                    char *qb = q_tile + row * (QCPR * 16) + (((lch >> 4) ^ qsw(row)) << 4);
-                    if (p.out_bits == 8) {
-                        v4i w = {qpack[q][0], qpack[q][1], qpack[q][2], qpack[q][3]};
-                        *reinterpret_cast<v4i *>(qb) = w;
-                    } else {
-                        v2i w = {qpack[q][0], qpack[q][1]};
-                        *reinterpret_cast<v2i *>(qb) = w;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < C::PT; ++q) {
-                    if (pix[q] >= p.M) continue;
-                    const size_t elem = (size_t)pix[q] * p.Cout + ch;
-                    if constexpr (RES) {
-                        if (p.res_out) {
-                            if (p.res_out_bits == 16) {
-                                v4i *dst = reinterpret_cast<v4i *>((uint16_t *)p.res_out + elem);
-                                v4i a = {rpack[q][0], rpack[q][1], rpack[q][2], rpack[q][3]};
-                                v4i b = {rpack[q][4], rpack[q][5], rpack[q][6], rpack[q][7]};
-                                dst[0] = a;
-                                dst[1] = b;
-                            } else {
-    #pragma unroll
-                                for (int i = 0; i < 4; ++i) {
-                                    v4i w = {rpack[q][4 * i], rpack[q][4 * i + 1], rpack[q][4 * i + 2],
-                                             rpack[q][4 * i + 3]};
-                                    reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[i] = w;
-                                }
-                            }
-                        }
-                    }
-                    if (!RES || p.out_q) {
-                        if (p.out_bits == 8) {
-                            v4i w = {qpack[q][0], qpack[q][1], qpack[q][2], qpack[q][3]};
-                            *reinterpret_cast<v4i *>((char *)p.out_q + elem) = w;
-                        } else {
-                            v2i w = {qpack[q][0], qpack[q][1]};
-                            *reinterpret_cast<v2i *>((char *)p.out_q + (elem >> 1)) = w;
-                        }
-                    }
-                }
-            }
-            if constexpr (RES) {
-                if (ovf && p.res_out && (STAGED || p.res_out_bits == 16)) atomicOr(p.flags, 1);
-            }
-        }
-    }
-    if constexpr (STAGED) {
-        __syncthreads();
-        const int t = threadIdx.x;
-        if constexpr (RES) {
-            if (p.res_out) {
-#pragma unroll
-                for (int i = 0; i < C::BM * RCPR / 256; ++i) {
-                    const int idx = t + 256 * i;
-                    const int row = idx / RCPR, j = idx % RCPR;
-                    if (m0 + row < p.M) {
-                        const v4i v = *reinterpret_cast<const v4i *>(res_tile + idx * 16);
-                        char *dst = (char *)p.res_out + ((size_t)(m0 + row) * p.Cout + c0) * 2 + ((j ^ rsw(row)) << 4);
-                        *reinterpret_cast<v4i *>(dst) = v;
-                    }
-                }
-            }
-        }
-        if (!RES || p.out_q) {
-#pragma unroll
-            for (int i = 0; i < (C::BM * QCPR + 255) / 256; ++i) {
-                const int idx = t + 256 * i;
-                const int row = idx / QCPR, j = idx % QCPR;
-                if (idx < C::BM * QCPR && m0 + row < p.M) {
-                    const size_t e0 = (size_t)(m0 + row) * p.Cout + c0 + ((j ^ qsw(row)) << 4);
-                    if (p.out_bits == 8) {
-                        *reinterpret_cast<v4i *>((char *)p.out_q + e0) = *reinterpret_cast<const v4i *>(q_tile + idx * 16);
-                    } else {
-                        *reinterpret_cast<v2i *>((char *)p.out_q + (e0 >> 1)) =
-                            *reinterpret_cast<const v2i *>(q_tile + idx * 16);
-                    }
-                }
-            }
-        }
-    }
+    if constexpr (FAST)
+        epilogue_fast<C, EPI, DUAL>(p, acc, acc2, m0, c0, smem, res_tile);
+    else
+        epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
 
 using T0 = Cfg<128, 128, 2, 2>;
@@ -593,6 +608,8 @@ bool raise_lds_limits() {
 int pick_tile(int M, int Cout, bool dual) {
     // Enough workgroups to fill 256 CUs a few times over, the largest tile that allows it.
     auto nwg = [&](int t) { return ((M + kTiles[t].BM - 1) / kTiles[t].BM) * (Cout / kTiles[t].BN); };
+    // two accumulator sets: only the 32-channel-per-wave tiles stay within 256 VGPRs without spilling
+    if (dual) return nwg(3) >= 512 ? 3 : 2;
     if (Cout % 128 == 0 && nwg(0) >= 1024) return 0;
     if (nwg(1) >= 1024 && !dual) return 1;
     if (Cout % 128 == 0 && nwg(0) >= 512) return 0;
@@ -647,17 +664,19 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.out_q = a->out_q, p.out_bits = a->out_bits, p.q_lo = a->q_lo, p.q_hi = a->q_hi, p.mq = a->mq, p.eq = a->eq;
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
     p.flags = a->flags;
-    // scalar dyadic tables use the conv epilogues' fast path: e must be in [33, 62] (see requant_table)
-    auto e_ok = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; };
+    const bool fast = a->fast_tables != 0;
+    auto e_fast = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62; };
+    auto e_any = [](int ek) { return (ek & 0xff) >= 1 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; };
     if (a->epilogue == HAWQ_EPI_RESIDUAL) {
         if (a->out_q) {
-            HAWQ_REQUIRE(e_ok(a->eq) && a->mq >= 0, "hawq_conv2d: (mq, eq) must satisfy 33 <= e <= 62");
+            HAWQ_REQUIRE(a->mq >= 0 && e_any(a->eq), "hawq_conv2d: bad (mq, eq)");
+            HAWQ_REQUIRE(!fast || (e_fast(a->eq) && (a->eq >> 8) == 0), "hawq_conv2d: fast_tables needs eq in [33,62], k == 0");
         } else {
             p.mq = 0, p.eq = 33;
         }
         if (!dual) {
-            HAWQ_REQUIRE(e_ok(a->e_id_scalar) && a->m_id_scalar >= 0,
-                         "hawq_conv2d: (m_id_scalar, e_id_scalar) must satisfy 33 <= e <= 62");
+            HAWQ_REQUIRE(a->m_id_scalar >= 0 && e_any(a->e_id_scalar), "hawq_conv2d: bad (m_id_scalar, e_id_scalar)");
+            HAWQ_REQUIRE(!fast || e_fast(a->e_id_scalar), "hawq_conv2d: fast_tables needs e_id_scalar in [33,62]");
         } else {
             p.m_id_s = 0, p.e_id_s = 33;
         }
@@ -700,7 +719,11 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     // 32-bit residual tensors use the generic (run-time bit-width, direct epilogue) kernels
     const bool wide_res = a->epilogue == HAWQ_EPI_RESIDUAL &&
                           ((!dual && a->res_in_bits == 32) || (a->res_out && a->res_out_bits == 32));
-    auto variant = [&](int ab, int wb) { return wide_res ? 0 : (ab == 8 && wb == 8 ? 1 : (ab == 4 && wb == 4 ? 2 : 0)); };
+    const bool needs_tables = slot == 1 || slot == 2;
+    auto variant = [&](int ab, int wb) {
+        if (wide_res || (needs_tables && !fast)) return 0;
+        return ab == 8 && wb == 8 ? 1 : (ab == 4 && wb == 4 ? 2 : 0);
+    };
     KernelFn fn;
     int lds = ti.lds;
     if (dual) {

@@ -19,16 +19,18 @@ Integer semantics follow SURVEY.md App. A; the graph is q_resnet.py:53-74 / 114-
 from __future__ import annotations
 
 import ctypes as C
+import os
 from functools import partial
 
 import numpy as np
 import torch
 
 from . import _lib, packing
-from .quant_utils import requant_table
+from .quant_utils import requant_table, tables_are_fast
 
 
 RES_VBITS = 20  # residual / pooled values are 16-bit-ish (uint16 storage saturates at 65535)
+U16_VBITS = 17  # tie-freeness proofs for values that live in uint16 residual tensors (< 2^16 unless flagged)
 
 
 def _i32(arr, dev):
@@ -92,7 +94,7 @@ class IntegerEngine:
     instead of re-deriving them from the float parameters."""
 
     def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
-                 keep_accumulators: bool = False):
+                 keep_accumulators: bool = False, fast: bool = True):
         if not model.is_frozen():
             raise RuntimeError("IntegerEngine needs a frozen model (freeze_model) - ranges must be fixed")
         _lib.load()
@@ -104,6 +106,7 @@ class IntegerEngine:
         self.from_buffers = from_buffers
         self.use_graph = use_graph
         self.keep_acc = keep_accumulators
+        self.fast = fast  # False forces the exact general kernels everywhere (reference for tests)
         self.stream = torch.cuda.Stream(device=self.dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._batch = None
@@ -157,7 +160,8 @@ class IntegerEngine:
                     s_n = self._scale(act)
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
-                               rng=_act_range(act.activation_bit, act.quant_mode))
+                               rng=_act_range(act.activation_bit, act.quant_mode),
+                               fast=tables_are_fast(mm, ee, c.vbits))
                     s_x, bits_x = s_n, ent['out_bits']
                 else:
                     ent['s_last'] = s_x
@@ -167,12 +171,20 @@ class IntegerEngine:
             last = d['convs'][-1]
             mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o, vbits=last['conv'].vbits)
             last.update(m=_i32(mm, dev), e=_i32(ee, dev))
+            fast = tables_are_fast(mm, ee, last['conv'].vbits)
             if d['resize']:
                 m1, e1 = requant_table(s_a, d['ident'].s_w, s_o, vbits=d['ident'].vbits)
                 d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
+                fast = fast and tables_are_fast(m1, e1, d['ident'].vbits)
             else:
                 m1, e1 = requant_table(s_prev, one, s_o, vbits=RES_VBITS)
                 d['m_id_s'], d['e_id_s'] = int(m1[0]), int(e1[0])
+                fast = fast and tables_are_fast(m1, e1, U16_VBITS, allow_shift=True)
+            last['fast'] = fast
+            # the next unit's block-input QuantAct is fused into this launch: its table must be fast too
+            if units:
+                prev_last = units[-1]['convs'][-1]
+                prev_last['fast'] = prev_last['fast'] and tables_are_fast([d['mq']], [d['eq']], U16_VBITS)
             s_prev = s_o
             units.append(d)
         P['units'] = units
@@ -258,6 +270,8 @@ class IntegerEngine:
                 a.in_bits, a.w_bits = x_bits, c.w_bits
                 a.m, a.e = ent['m'].data_ptr(), ent['e'].data_ptr()
                 a.flags = self.flags.data_ptr()
+                a.fast_tables = int(bool(ent.get('fast', False)) and self.res_bits == 16 and self.fast)
+                a.tile = int(os.environ.get("HAWQ_TILE_RES" if ci == len(u['convs']) - 1 else "HAWQ_TILE_REQ", "0"))
                 tap_name = f"{u['name']}.quant_convbn{ci + 1}"
                 if ci < len(u['convs']) - 1:
                     out = self._alloc(N * ho * wo * c.cout * ent['out_bits'] // 8, torch.uint8)

@@ -19,8 +19,10 @@
  *     (c0|c1<<8|c2<<16|c3<<24) | (c4|c5<<8|c6<<16|c7<<24)<<4  (so that two mask ops unpack it
  *     into two int8x4 words in channel order).  16-bit residual tensors are uint16
  *     (post-ReLU values; overflow beyond 65535 sets bit 0 of *flags and saturates) or int32.
- *   - dyadic requantisation tables are (m, e) pairs with 0 <= m < 2^31, 1 <= e <= 62:
- *     q = round_half_even(acc * m / 2^e)  (quant_utils.py:188-213, 404-408).
+ *   - dyadic requantisation tables are (m, ek) pairs, ek = e | k << 8, 0 <= m < 2^31, 1 <= e <= 62:
+ *     q = round_half_even(((acc << k) * m) / 2^e)  (quant_utils.py:188-213, 404-408); the
+ *     pre-shift k (|acc << k| < 2^31) lets the host lift small e to >= 33 without changing the
+ *     rational m * 2^k / 2^e (hawq_amd.quant_utils.requant_table).
  */
 #ifndef HAWQ_MI355_H
 #define HAWQ_MI355_H
@@ -94,6 +96,13 @@ typedef struct hawq_conv_args {
     int32_t ldo, n_valid;
     int32_t *flags;       /* device int32: bit0 = uint16 residual overflow                     */
     int32_t tile;         /* 0 = heuristic; else tile config id (see hawq_conv2d_num_tiles)    */
+    int32_t fast_tables;  /* caller asserts the "fast contract" for EVERY dyadic table of this call:
+                             e in [33,62]; k == 0 in per-channel tables and in (mq,eq); no exact
+                             rounding tie is possible for the value ranges involved (the host proves
+                             this from the trailing zeros of m - hawq_amd.quant_utils.tables_are_fast).
+                             Enables the 2-instruction requant path and the LDS-staged coalesced
+                             epilogue (8/8 and 4/4 operand widths, 16-bit residuals).  0 = exact
+                             general path (any e in [1,62], any k, ties handled).                 */
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);

@@ -63,10 +63,11 @@ def odyadic(orc, acc, m, ek, clamp=None):
 
 
 def rand_tables(rng, cout, lo=2e-4, hi=3e-3):
-    """random per-channel requant ratios -> device-contract (m, e)."""
+    """random per-channel requant ratios -> device-contract (m, e).  Dividing by a non-trivial
+    output scale gives m a full 31-bit mantissa, as in a real network."""
     from hawq_amd.quant_utils import requant_table
-    r = torch.from_numpy(rng.uniform(lo, hi, cout).astype(f32))
-    return requant_table(torch.ones(1), r, torch.ones(1))
+    r = torch.from_numpy((rng.uniform(lo, hi, cout) * 0.7).astype(f32))
+    return requant_table(torch.ones(1), r, torch.tensor([0.7]))
 
 
 def make_conv(rng, n, h, w, cin, cout, k, a_bits, w_bits):
@@ -130,18 +131,27 @@ def test_conv_identity_weights_asymmetric(lib):
     assert np.array_equal(out.cpu().numpy().reshape(n, h, w, c).transpose(0, 3, 1, 2), x)
 
 
+@pytest.mark.parametrize("fast", [0, 1])
 @pytest.mark.parametrize("out_bits", [8, 4])
 @pytest.mark.parametrize("bits", [(8, 8), (4, 4)])
-def test_conv_requant_epilogue(lib, orc, bits, out_bits):
+def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
+    """fast=1: host-proved tie-free tables -> LDS-staged 2-instruction requant kernels;
+    fast=0: exact general kernels, with forced exact .5 ties."""
+    from hawq_amd.quant_utils import tables_are_fast
     rng = np.random.default_rng(5)
     n, h, w, cin, cout, k = 2, 12, 12, 128, 128, 3
     x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
     acc = orc.conv2d(x, wt, b, 1, 1)
     m, e = rand_tables(rng, cout, 2e-5 if bits[0] == 8 else 2e-3, 3e-4 if bits[0] == 8 else 2e-2)
-    m[0], e[0] = 1 << 30, 33 | (1 << 8)  # ratio 1/4 (e=32 lifted by k=1): produces exact .5 ties
+    if fast:
+        assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
+    else:
+        m[0], e[0] = 1 << 30, 33 | (1 << 8)  # ratio 1/4 (e=32 lifted by k=1): produces exact .5 ties
+        assert not tables_are_fast(m, e, 20)
     lo, hi = (-128, 127) if out_bits == 8 else (0, 15)
     ref = odyadic(orc, np.maximum(acc, 0), m, e, (lo, hi))
     a, keep = conv_args(lib, x, wt, b, 1, 1, *bits)
+    a.fast_tables = fast
     md, ed = dev(m), dev(e)
     out = torch.zeros(ref.size * out_bits // 8, dtype=torch.uint8, device='cuda')
     a.epilogue, a.relu, a.m, a.e = lib.EPI_REQUANT, 1, md.data_ptr(), ed.data_ptr()
@@ -155,9 +165,11 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits):
         assert np.array_equal(unpack_q(out, (n, h, w, cout), 8), odyadic(orc, acc, m, e, (lo, hi)))
 
 
+@pytest.mark.parametrize("fast", [0, 1])
 @pytest.mark.parametrize("res_bits", [16, 32])
 @pytest.mark.parametrize("dual", [False, True])
-def test_conv_residual_epilogue(lib, orc, dual, res_bits):
+def test_conv_residual_epilogue(lib, orc, dual, res_bits, fast):
+    from hawq_amd.quant_utils import tables_are_fast
     rng = np.random.default_rng(11 + dual)
     n, h, w, cin, cout = 2, 14, 14, 64, 256
     x, wt, b = make_conv(rng, n, h, w, cin, cout, 1, 8, 8)
@@ -178,7 +190,7 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits):
     else:
         res = rng.integers(0, 60000, (n, cout, h, w)).astype(np.int64)
         from hawq_amd.quant_utils import requant_table
-        m1, e1 = requant_table(torch.tensor([0.37]), torch.ones(1), torch.ones(1))
+        m1, e1 = requant_table(torch.tensor([0.37 * 0.7]), torch.ones(1), torch.tensor([0.7]))
         idq = odyadic(orc, res, m1, e1)
         keep['res'] = dev(nhwc(res).astype(np.uint16 if res_bits == 16 else np.int32))
         a.res_in, a.res_in_bits = keep['res'].data_ptr(), res_bits
@@ -186,7 +198,7 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits):
     ref_res = np.maximum(odyadic(orc, acc, m2, e2) + idq, 0)
     assert ref_res.max() < 65536
     from hawq_amd.quant_utils import requant_table
-    mq, eq = requant_table(torch.tensor([0.0039]), torch.ones(1), torch.ones(1))
+    mq, eq = requant_table(torch.tensor([0.0039 * 0.7]), torch.ones(1), torch.tensor([0.7]))
     ref_q = odyadic(orc, ref_res, mq, eq, (0, 127))
     md, ed = dev(m2), dev(e2)
     flags = torch.zeros(1, dtype=torch.int32, device='cuda')
@@ -195,6 +207,11 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits):
     a.epilogue, a.m, a.e, a.flags = lib.EPI_RESIDUAL, md.data_ptr(), ed.data_ptr(), flags.data_ptr()
     a.res_out, a.res_out_bits = out_res.data_ptr(), res_bits
     a.out_q, a.out_bits, a.q_lo, a.q_hi, a.mq, a.eq = out_q.data_ptr(), 8, 0, 127, int(mq[0]), int(eq[0])
+    if fast:
+        vb = int(np.abs(acc).max()).bit_length() + 1
+        assert tables_are_fast(m2, e2, vb) and tables_are_fast(m1, e1, 22 if dual else 17, allow_shift=not dual)
+        assert tables_are_fast(mq, eq, 17)
+    a.fast_tables = fast  # (32-bit residuals run the general kernels either way)
     lib.call("hawq_conv2d", C.byref(a), stream())
     got = out_res.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2)
     assert np.array_equal(got, ref_res)

@@ -1,0 +1,159 @@
+"""CPU tests of the host-side logic of hawq_amd (no GPU, no reference needed)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """The C-ABI library loads here (no GPU needed) and exports everything include/hawq_mi355.h declares."""
+    from hawq_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "hawq_mi355.h")).read()
+    declared = set(re.findall(r"\b(hawq_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert set(_lib.SIGNATURES) | {"hawq_last_error"} == declared
+    assert lib.hawq_abi_version() == 1
+    assert ctypes.sizeof(_lib.ConvArgs) % 8 == 0
+
+
+def test_requant_table_matches_oracle_and_lifts_exactly():
+    from hawq_amd.quant_utils import requant_table, tables_are_fast
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    s_w = torch.from_numpy(rng.uniform(1e-4, 3.0, 200).astype(np.float32))
+    s_a, s_o = torch.tensor([0.0213]), torch.tensor([0.047])
+    m, ek = requant_table(s_a, s_w, s_o, vbits=20)
+    mo, eo = oracle.requant_table(s_a.numpy(), s_w.numpy(), s_o.numpy())
+    e, k = ek & 0xff, ek >> 8
+    assert (e >= 33).all() and ((m < 2 ** 31) & (m >= 0)).all()
+    # same rational: m * 2^k / 2^e == mo / 2^eo   (mo may be 2^31 where m is 2^30)
+    assert all(int(a) << (int(kk) + 62 - int(ee)) == int(b) << (62 - int(eb)) for a, kk, ee, b, eb in zip(m, k, e, mo, eo))
+    acc = rng.integers(-2 ** 19, 2 ** 19, (4, 200, 3)).astype(np.int64)
+    ref = oracle.dyadic(acc, mo, eo)
+    got = oracle.dyadic(acc << k.reshape(1, -1, 1), m.astype(np.int64), e.astype(np.int32))
+    assert np.array_equal(ref, got)
+    with pytest.raises(ValueError):
+        requant_table(torch.tensor([1.0]), torch.tensor([64.0]), torch.tensor([1.0]), vbits=24)
+    # tie-freeness proof: a power-of-two ratio can tie, a generic one cannot for narrow inputs
+    assert not tables_are_fast(np.array([1 << 30]), np.array([34]), 20)
+    assert tables_are_fast(np.array([(1 << 30) + 1]), np.array([40]), 24)
+    assert not tables_are_fast(np.array([(1 << 30) + 1]), np.array([33 | (1 << 8)]), 24)
+    assert tables_are_fast(np.array([(1 << 30) + 1]), np.array([33 | (1 << 8)]), 24, allow_shift=True)
+
+
+def test_tie_free_proof_is_sound_by_brute_force():
+    """For small parameters enumerate every v: whenever tables_are_fast says yes, half-up == half-even."""
+    from hawq_amd.quant_utils import tables_are_fast
+    rng = np.random.default_rng(1)
+    checked = 0
+    for _ in range(300):
+        e = int(rng.integers(33, 40))
+        tz = int(rng.integers(0, 31))
+        m = (int(rng.integers(1, 2 ** (31 - tz))) | 1) << tz
+        if m >= 2 ** 31:
+            continue
+        vbits = int(rng.integers(4, 12))
+        if not tables_are_fast(np.array([m]), np.array([e]), vbits):
+            continue
+        v = np.arange(-(2 ** vbits) + 1, 2 ** vbits, dtype=object)
+        p = v * m
+        half = 1 << (e - 1)
+        up = (p + half) >> e
+        rem = p - ((p >> e) << e)
+        even = (p >> e) + np.array([1 if (r > half or (r == half and (int(f) & 1))) else 0 for r, f in zip(rem, p >> e)], dtype=object)
+        assert (up == even).all()
+        checked += 1
+    assert checked > 50
+
+
+def test_packing_roundtrip_and_layout():
+    from hawq_amd.packing import pack_conv_weight, pack_hawq4, pack_stem_weight, unpack_hawq4
+    rng = np.random.default_rng(0)
+    v = rng.integers(-8, 8, (3, 5, 16))
+    assert np.array_equal(unpack_hawq4(pack_hawq4(v), signed=True), v)
+    g = np.arange(8)
+    b = pack_hawq4(g[None, :])[0]
+    assert list(b) == [0 | 4 << 4, 1 | 5 << 4, 2 | 6 << 4, 3 | 7 << 4]
+    w = rng.integers(-127, 128, (64, 64, 3, 3))
+    p = pack_conv_weight(w, 8).view(np.int8).reshape(64, 3, 3, 64)
+    assert np.array_equal(p.transpose(0, 3, 1, 2), w)
+    ws = rng.integers(-127, 128, (64, 3, 7, 7))
+    ps = pack_stem_weight(ws).view(np.int8).reshape(64, 7, 8, 4)
+    assert np.array_equal(ps[:, :, :7, :3].transpose(0, 3, 1, 2), ws) and not ps[:, :, 7].any() and not ps[..., 3].any()
+
+
+def test_bit_schedules_and_module_tree():
+    from hawq_amd.api import build_quantized_resnet
+    from hawq_amd.bit_schedules import bit_config_dict, module_names
+    assert len(bit_config_dict) == 26
+    for arch, scheme in H.NET_CONFIGS:
+        q = build_quantized_resnet(arch, scheme, seed=None)
+        names = dict(q.named_modules())
+        cfg = bit_config_dict[f"bit_config_{arch}_{scheme}"]
+        assert list(cfg) == module_names(arch)
+        for n, bits in cfg.items():
+            m = names[n]
+            assert (m.activation_bit if hasattr(m, "activation_bit") else m.weight_bit) == bits
+            if hasattr(m, "activation_bit"):
+                assert m.quant_mode == ("asymmetric" if bits == 4 else "symmetric")
+    sd = build_quantized_resnet("resnet50", "uniform8", seed=None).state_dict()
+    for key in ("stage1.unit1.quant_convbn1.conv.weight", "stage1.unit1.quant_convbn1.weight_integer",
+                "stage1.unit1.quant_convbn1.convbn_scaling_factor", "stage1.unit1.quant_act.x_min",
+                "stage1.unit1.quant_act.act_scaling_factor", "quant_output.fc_scaling_factor",
+                "quant_output.weight_integer", "quant_init_convbn.bn.running_var",
+                "stage1.unit1.quant_identity_convbn.bias_integer"):
+        assert key in sd, key
+
+
+def test_host_preparation_matches_oracle_and_freeze_semantics():
+    """QuantBnConv2d.prepare / QuantLinear.prepare (host side, IEEE) == the oracle's restatement;
+    freeze/unfreeze toggle the reference's flags; the product path refuses CPU tensors."""
+    from hawq_amd import quant_modules as qm
+    from hawq_amd.api import build_quantized_resnet
+    from oracle import oracle
+    q = build_quantized_resnet("resnet18", "bops_0.5", seed=0)
+    u = getattr(q, "stage2.unit1")
+    s_a = torch.tensor([0.0173])
+    for mod in (u.quant_convbn1, u.quant_identity_convbn):
+        mod.prepare(s_a)
+        w_f, b_f = oracle.fold_bn(mod.conv.weight.detach().numpy(), mod.bn.weight.detach().numpy(),
+                                  mod.bn.bias.detach().numpy(), mod.bn.running_mean.numpy(),
+                                  mod.bn.running_var.numpy(), mod.bn.eps)
+        w_int, s_w = oracle.quantize_weight(w_f, mod.weight_bit)
+        b_int, _ = oracle.quantize_bias(b_f, s_w, s_a.numpy())
+        assert np.array_equal(mod.weight_integer.numpy(), w_int)
+        assert np.array_equal(mod.convbn_scaling_factor.numpy(), s_w)
+        assert np.array_equal(mod.bias_integer.numpy().astype(np.int64), b_int)
+    fc = q.quant_output
+    fc.prepare(s_a)
+    w_int, s_fc = oracle.quantize_weight(fc.weight.detach().numpy(), 8)
+    assert np.array_equal(fc.weight_integer.numpy(), w_int) and np.array_equal(fc.fc_scaling_factor.numpy(), s_fc)
+    assert not q.is_frozen()
+    qm.freeze_model(q)
+    assert q.is_frozen() and u.quant_convbn1.fix_BN and not u.quant_act.running_stat
+    qm.unfreeze_model(q)
+    assert not q.is_frozen() and u.quant_act.running_stat
+    with pytest.raises(RuntimeError):
+        q.forward_modules(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(ValueError):
+        qm.QuantAct(quant_mode="bogus")(torch.zeros(1, 3, 4, 4))
+
+
+def test_roofline_model_reproduces_survey_numbers():
+    from hawq_amd import roofline
+    want = {("resnet18", "uniform8"): 1.419, ("resnet18", "uniform4"): 1.176, ("resnet18", "bops_0.5"): 1.343,
+            ("resnet50", "uniform8"): 7.991, ("resnet50", "uniform4"): 6.804, ("resnet50", "bops_0.5"): 7.821}
+    for (a, s), gb in want.items():
+        assert abs(roofline.algorithmic_bytes(a, s, 128) / 1e9 - gb) < 5e-4
+    assert abs(roofline.macs("resnet50", "uniform8", 128) / 1e9 - 493.8) < 0.1
+    assert abs(roofline.macs("resnet18", "uniform8", 128) / 1e9 - 232.2) < 0.1
