@@ -176,7 +176,8 @@ def main():
             "config": {"workload": f"{args.arch}_{args.scheme}_b{args.batch}", "arch": args.arch,
                        "scheme": args.scheme, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
-                       "residual_uint16_overflow": overflow},
+                       "residual_uint16_overflow": overflow,
+                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}"},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": "one hipGraph launch = whole forward of one batch",

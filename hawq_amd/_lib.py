@@ -32,7 +32,7 @@ class ConvArgs(C.Structure):
         ("res_out", vp), ("res_out_bits", i32),
         ("out_q", vp), ("out_bits", i32), ("q_lo", i32), ("q_hi", i32), ("mq", i32), ("eq", i32),
         ("out_acc", vp), ("out_f32", vp), ("fscale", vp), ("ldo", i32), ("n_valid", i32),
-        ("flags", vp), ("tile", i32), ("fast_tables", i32),
+        ("flags", vp), ("tile", i32), ("ctab", vp), ("ctab_id", vp), ("fast_tables", i32),
     ]
 
 

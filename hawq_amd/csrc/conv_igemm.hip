@@ -41,6 +41,7 @@ struct ConvP {
     const float *fscale;
     int ldo, n_valid;
     int32_t *flags;
+    const int32_t *ctab, *ctab_id;
 };
 
 template <int BM_, int BN_, int WM_, int WN_>
@@ -380,10 +381,9 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     const int wave_m = wave % C::WM, wave_c = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
     const int lrow0 = wave_m * (C::PT * 32) + l31;  // tile-local pixel row of pixel tile 0
-    const int relu_floor = p.relu ? 0 : (int)0x80000000;
     const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
     const int kid = p.e_id_s >> 8;  // pre-shift of the scalar identity table, applied while unpacking
-    int omax = 0;
+    unsigned oor = 0;               // OR of all residual outputs: bits >= 16 set <=> uint16 overflow
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
         const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;  // tile-local first channel of this lane
@@ -407,31 +407,35 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
         int rpack[QPER][RES ? 8 : 1];  // 16 x uint16
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const v4i b4 = ld4(p.bias + ch + 4 * g), m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
-            const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
-            const DyNt dm[4] = {dynt_prepare(m4.x, e4.x), dynt_prepare(m4.y, e4.y), dynt_prepare(m4.z, e4.z),
-                                dynt_prepare(m4.w, e4.w)};
-            int bb2[4] = {0, 0, 0, 0};
-            DyNt di[4] = {dids, dids, dids, dids};
-            if constexpr (DUAL) {
-                const v4i b2 = ld4(p.bias2 + ch + 4 * g), mi = ld4(p.m_id + ch + 4 * g), ei = ld4(p.e_id + ch + 4 * g);
-                bb2[0] = b2.x, bb2[1] = b2.y, bb2[2] = b2.z, bb2[3] = b2.w;
-                di[0] = dynt_prepare(mi.x, ei.x), di[1] = dynt_prepare(mi.y, ei.y);
-                di[2] = dynt_prepare(mi.z, ei.z), di[3] = dynt_prepare(mi.w, ei.w);
+            // fused constants {m, s, C} with C = bias*m + 2^(e-1): (acc+bias)*m + 2^(e-1) == acc*m + C
+            DyNt dm[4], di[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i t = ld4(p.ctab + (ch + 4 * g + j) * 4);
+                dm[j].m = t.x, dm[j].s = t.y;
+                dm[j].add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
+                if constexpr (DUAL) {
+                    const v4i u = ld4(p.ctab_id + (ch + 4 * g + j) * 4);
+                    di[j].m = u.x, di[j].s = u.y;
+                    di[j].add = (long long)(((unsigned long long)(unsigned)u.w << 32) | (unsigned)u.z);
+                } else {
+                    di[j] = dids;
+                }
             }
 #pragma unroll
             for (int qq = 0; qq < QPER; ++qq) {
                 const int q = qp * QPER + qq;
                 int qv[4];
                 if constexpr (!RES) {
+                    // ReLU commutes with the (monotone, 0 -> 0) requantisation: it is folded into q_lo
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        qv[j] = dyadic_nt(max(acc[c][q][4 * g + j] + bb[j], relu_floor), dm[j]);
+                        qv[j] = min(max(dyadic_nt(acc[c][q][4 * g + j], dm[j]), p.q_lo), p.q_hi);
                 } else {
                     int idin[4], o[4];
                     if constexpr (DUAL) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) idin[j] = acc2[DUAL ? c : 0][DUAL ? q : 0][4 * g + j] + bb2[j];
+                        for (int j = 0; j < 4; ++j) idin[j] = acc2[DUAL ? c : 0][DUAL ? q : 0][4 * g + j];
                     } else {
                         const unsigned w0 = (unsigned)rin[q][g >> 1][(g & 1) * 2], w1 = (unsigned)rin[q][g >> 1][(g & 1) * 2 + 1];
                         idin[0] = (int)((w0 & 0xffffu) << kid), idin[1] = (int)((w0 >> 16) << kid);
@@ -439,17 +443,15 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int a = dyadic_nt(acc[c][q][4 * g + j] + bb[j], dm[j]);
+                        const int a = dyadic_nt(acc[c][q][4 * g + j], dm[j]);
                         const int b = dyadic_nt(idin[j], di[j]);
                         o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
-                        omax = max(omax, o[j]);
-                        qv[j] = dyadic_nt(o[j], dq);
+                        qv[j] = min(dyadic_nt(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
                     }
+                    oor |= (unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3]);
                     rpack[qq][RES ? 2 * g : 0] = pack2_u16_sat(o[0], o[1]);
                     rpack[qq][RES ? 2 * g + 1 : 0] = pack2_u16_sat(o[2], o[3]);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) qv[j] = min(max(qv[j], p.q_lo), p.q_hi);
                 const int w = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
                 if (p.out_bits == 8) {
                     qpack[qq][g] = w;
@@ -482,7 +484,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
         }
         }  // qp
     }
-    if (RES && omax > 65535 && p.res_out) atomicOr(p.flags, 1);  // rows beyond M never reach memory but may flag: harmless
+    if (RES && (oor >> 16) != 0 && p.res_out) atomicOr(p.flags, 1);  // rows beyond M never reach memory but may flag: harmless
     __syncthreads();
     const int t = threadIdx.x;
     if constexpr (RES) {
@@ -664,7 +666,14 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.out_q = a->out_q, p.out_bits = a->out_bits, p.q_lo = a->q_lo, p.q_hi = a->q_hi, p.mq = a->mq, p.eq = a->eq;
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
     p.flags = a->flags;
+    p.ctab = a->ctab, p.ctab_id = a->ctab_id;
     const bool fast = a->fast_tables != 0;
+    if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
+        HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
+        if (a->epilogue == HAWQ_EPI_REQUANT && a->relu && p.q_lo < 0) p.q_lo = 0;  // ReLU folded into the clamp
+        HAWQ_REQUIRE(a->epilogue != HAWQ_EPI_RESIDUAL || !a->out_q || a->q_lo <= 0,
+                     "hawq_conv2d: fast RESIDUAL needs q_lo <= 0");
+    }
     auto e_fast = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62; };
     auto e_any = [](int ek) { return (ek & 0xff) >= 1 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; };
     if (a->epilogue == HAWQ_EPI_RESIDUAL) {

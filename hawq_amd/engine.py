@@ -162,6 +162,8 @@ class IntegerEngine:
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
                                rng=_act_range(act.activation_bit, act.quant_mode),
                                fast=tables_are_fast(mm, ee, c.vbits))
+                    if ent['fast']:
+                        ent['ctab'] = _i32(packing.pack_ctab(c.b_host, mm, ee), dev)
                     s_x, bits_x = s_n, ent['out_bits']
                 else:
                     ent['s_last'] = s_x
@@ -172,10 +174,15 @@ class IntegerEngine:
             mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o, vbits=last['conv'].vbits)
             last.update(m=_i32(mm, dev), e=_i32(ee, dev))
             fast = tables_are_fast(mm, ee, last['conv'].vbits)
+            if fast:
+                last['ctab'] = _i32(packing.pack_ctab(last['conv'].b_host, mm, ee), dev)
             if d['resize']:
                 m1, e1 = requant_table(s_a, d['ident'].s_w, s_o, vbits=d['ident'].vbits)
                 d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
-                fast = fast and tables_are_fast(m1, e1, d['ident'].vbits)
+                if tables_are_fast(m1, e1, d['ident'].vbits):
+                    d['ctab_id'] = _i32(packing.pack_ctab(d['ident'].b_host, m1, e1), dev)
+                else:
+                    fast = False
             else:
                 m1, e1 = requant_table(s_prev, one, s_o, vbits=RES_VBITS)
                 d['m_id_s'], d['e_id_s'] = int(m1[0]), int(e1[0])
@@ -227,6 +234,7 @@ class IntegerEngine:
         P, dev = self.P, self.dev
         ops, keep = _OpList(), []
         self.acc_taps = {}
+        self.n_fast = self.n_conv = 0  # how many conv launches run the fast-contract kernels
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
         rdt = torch.uint16 if self.res_bits == 16 else torch.int32
@@ -271,6 +279,12 @@ class IntegerEngine:
                 a.m, a.e = ent['m'].data_ptr(), ent['e'].data_ptr()
                 a.flags = self.flags.data_ptr()
                 a.fast_tables = int(bool(ent.get('fast', False)) and self.res_bits == 16 and self.fast)
+                if a.fast_tables:
+                    a.ctab = ent['ctab'].data_ptr()
+                    if ci == len(u['convs']) - 1 and u['resize']:
+                        a.ctab_id = u['ctab_id'].data_ptr()
+                self.n_fast += int(a.fast_tables)
+                self.n_conv += 1
                 a.tile = int(os.environ.get("HAWQ_TILE_RES" if ci == len(u['convs']) - 1 else "HAWQ_TILE_REQ", "0"))
                 tap_name = f"{u['name']}.quant_convbn{ci + 1}"
                 if ci < len(u['convs']) - 1:

@@ -96,13 +96,16 @@ typedef struct hawq_conv_args {
     int32_t ldo, n_valid;
     int32_t *flags;       /* device int32: bit0 = uint16 residual overflow                     */
     int32_t tile;         /* 0 = heuristic; else tile config id (see hawq_conv2d_num_tiles)    */
+    const int32_t *ctab;    /* fast path only: [Cout][4] = {m, e-32, lo32(C), hi32(C)}, C = bias*m + 2^(e-1) */
+    const int32_t *ctab_id; /* fast path, second branch: same for (bias2, m_id, e_id)                   */
     int32_t fast_tables;  /* caller asserts the "fast contract" for EVERY dyadic table of this call:
                              e in [33,62]; k == 0 in per-channel tables and in (mq,eq); no exact
                              rounding tie is possible for the value ranges involved (the host proves
                              this from the trailing zeros of m - hawq_amd.quant_utils.tables_are_fast).
                              Enables the 2-instruction requant path and the LDS-staged coalesced
-                             epilogue (8/8 and 4/4 operand widths, 16-bit residuals).  0 = exact
-                             general path (any e in [1,62], any k, ties handled).                 */
+                             epilogue (8/8 and 4/4 operand widths, 16-bit residuals); needs ctab
+                             (and ctab_id with a second branch).  0 = exact general path (any e in
+                             [1,62], any k, ties handled) driven by bias / m / e.                 */
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);

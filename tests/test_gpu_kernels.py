@@ -152,6 +152,10 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
     ref = odyadic(orc, np.maximum(acc, 0), m, e, (lo, hi))
     a, keep = conv_args(lib, x, wt, b, 1, 1, *bits)
     a.fast_tables = fast
+    if fast:
+        from hawq_amd.packing import pack_ctab
+        keep['ctab'] = dev(pack_ctab(b, m, e))
+        a.ctab = keep['ctab'].data_ptr()
     md, ed = dev(m), dev(e)
     out = torch.zeros(ref.size * out_bits // 8, dtype=torch.uint8, device='cuda')
     a.epilogue, a.relu, a.m, a.e = lib.EPI_REQUANT, 1, md.data_ptr(), ed.data_ptr()
@@ -212,6 +216,13 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits, fast):
         assert tables_are_fast(m2, e2, vb) and tables_are_fast(m1, e1, 22 if dual else 17, allow_shift=not dual)
         assert tables_are_fast(mq, eq, 17)
     a.fast_tables = fast  # (32-bit residuals run the general kernels either way)
+    if fast:
+        from hawq_amd.packing import pack_ctab
+        keep['ctab'] = dev(pack_ctab(b, m2, e2))
+        a.ctab = keep['ctab'].data_ptr()
+        if dual:
+            keep['ctab_id'] = dev(pack_ctab(b2, m1, e1))
+            a.ctab_id = keep['ctab_id'].data_ptr()
     lib.call("hawq_conv2d", C.byref(a), stream())
     got = out_res.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2)
     assert np.array_equal(got, ref_res)
