@@ -47,7 +47,7 @@ __device__ __forceinline__ int32_t dyadic_rne(int32_t v, int32_t m, int32_t ek) 
 }
 
 // Fast path used by the conv epilogues when the HOST has proved, for every table entry, that
-//   (a) e >= 33 (s = e - 32 in [1,30]) and, for per-channel tables, k == 0, and
+//   (a) e >= 33 (s = e - 32 in [1,30]), |v << k| < 2^31, and
 //   (b) an exact tie cannot occur: a tie needs 2^(e-1) | (v << k) * m, i.e. tz(v) >= e-1-k-tz(m);
 //       with |v| < 2^vbits known that is impossible when tz(m) <= e - 1 - k - vbits
 //       (hawq_amd.quant_utils.tables_are_fast).
@@ -55,18 +55,19 @@ __device__ __forceinline__ int32_t dyadic_rne(int32_t v, int32_t m, int32_t ek) 
 // entirely in the high word and can be the 64-bit addend of ONE v_mad_i64_i32, and the quotient is
 // an arithmetic shift of the high word:  2 VALU instructions.
 struct DyNt {
-    int m, s;
-    long long add;  // 2^(e-1) = (1 << (s-1)) << 32
+    int m, s, k;
+    long long add;  // 2^(e-1) = (1 << (s-1)) << 32   (+ (bias << k) * m when the bias is folded in)
 };
 __device__ __forceinline__ DyNt dynt_prepare(int m, int ek) {
     DyNt c;
     c.m = m;
     c.s = (ek & 0xff) - 32;
+    c.k = ek >> 8;
     c.add = (long long)(1u << (c.s - 1)) << 32;
     return c;
 }
 __device__ __forceinline__ int32_t dyadic_nt(int32_t v, const DyNt &c) {
-    const long long t = (long long)v * (long long)c.m + c.add;
+    const long long t = (long long)(v << c.k) * (long long)c.m + c.add;
     return (int)(t >> 32) >> c.s;
 }
 

@@ -382,7 +382,6 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     const int l31 = lane & 31, h = lane >> 5;
     const int lrow0 = wave_m * (C::PT * 32) + l31;  // tile-local pixel row of pixel tile 0
     const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
-    const int kid = p.e_id_s >> 8;  // pre-shift of the scalar identity table, applied while unpacking
     unsigned oor = 0;               // OR of all residual outputs: bits >= 16 set <=> uint16 overflow
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
@@ -412,11 +411,11 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const v4i t = ld4(p.ctab + (ch + 4 * g + j) * 4);
-                dm[j].m = t.x, dm[j].s = t.y;
+                dm[j].m = t.x, dm[j].s = t.y & 0xff, dm[j].k = t.y >> 8;
                 dm[j].add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
                 if constexpr (DUAL) {
                     const v4i u = ld4(p.ctab_id + (ch + 4 * g + j) * 4);
-                    di[j].m = u.x, di[j].s = u.y;
+                    di[j].m = u.x, di[j].s = u.y & 0xff, di[j].k = u.y >> 8;
                     di[j].add = (long long)(((unsigned long long)(unsigned)u.w << 32) | (unsigned)u.z);
                 } else {
                     di[j] = dids;
@@ -438,8 +437,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                         for (int j = 0; j < 4; ++j) idin[j] = acc2[DUAL ? c : 0][DUAL ? q : 0][4 * g + j];
                     } else {
                         const unsigned w0 = (unsigned)rin[q][g >> 1][(g & 1) * 2], w1 = (unsigned)rin[q][g >> 1][(g & 1) * 2 + 1];
-                        idin[0] = (int)((w0 & 0xffffu) << kid), idin[1] = (int)((w0 >> 16) << kid);
-                        idin[2] = (int)((w1 & 0xffffu) << kid), idin[3] = (int)((w1 >> 16) << kid);
+                        idin[0] = (int)(w0 & 0xffffu), idin[1] = (int)(w0 >> 16);
+                        idin[2] = (int)(w1 & 0xffffu), idin[3] = (int)(w1 >> 16);
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -679,7 +678,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (a->epilogue == HAWQ_EPI_RESIDUAL) {
         if (a->out_q) {
             HAWQ_REQUIRE(a->mq >= 0 && e_any(a->eq), "hawq_conv2d: bad (mq, eq)");
-            HAWQ_REQUIRE(!fast || (e_fast(a->eq) && (a->eq >> 8) == 0), "hawq_conv2d: fast_tables needs eq in [33,62], k == 0");
+            HAWQ_REQUIRE(!fast || e_fast(a->eq), "hawq_conv2d: fast_tables needs eq in [33,62]");
         } else {
             p.mq = 0, p.eq = 33;
         }

@@ -58,18 +58,19 @@ def pack_stem_weight(w_int: np.ndarray) -> np.ndarray:
 
 def pack_ctab(bias, m, ek) -> np.ndarray:
     """Fused per-channel requant constants of the fast conv epilogues: int32 [C][4] =
-    {m, s = e - 32, lo32(Cc), hi32(Cc)} with Cc = bias*m + 2^(e-1), so that
-    q = hi32(acc*m + Cc) >> s  ==  round_half_up(((acc + bias) * m) / 2^e)   (one v_mad_i64_i32 +
-    one v_ashrrev_i32).  Only valid for tables that satisfy the fast contract (k == 0, e >= 33)."""
+    {m, (e - 32) | k << 8, lo32(Cc), hi32(Cc)} with Cc = (bias << k)*m + 2^(e-1), so that
+    q = hi32((acc << k)*m + Cc) >> (e-32)  ==  round_half_up((((acc + bias) << k) * m) / 2^e)
+    (one shift, one v_mad_i64_i32, one v_ashrrev_i32).  Only valid for tables that satisfy the fast
+    contract (e >= 33, no tie possible)."""
     bias = np.asarray(bias, np.int64).reshape(-1)
     m = np.asarray(m, np.int64).reshape(-1)
     ek = np.asarray(ek, np.int64).reshape(-1)
     e, k = ek & 0xff, ek >> 8
-    assert (k == 0).all() and (e >= 33).all() and (e <= 62).all(), "pack_ctab needs fast-contract tables"
-    cc = bias * m + (np.int64(1) << (e - 1))
+    assert (e >= 33).all() and (e <= 62).all() and (k >= 0).all(), "pack_ctab needs fast-contract tables"
+    cc = (bias << k) * m + (np.int64(1) << (e - 1))
     out = np.empty((bias.size, 4), np.int32)
     out[:, 0] = m.astype(np.int32)
-    out[:, 1] = (e - 32).astype(np.int32)
+    out[:, 1] = ((e - 32) | (k << 8)).astype(np.int32)
     out[:, 2] = (cc & 0xffffffff).astype(np.uint32).view(np.int32)
     out[:, 3] = (cc >> 32).astype(np.int32)
     return out

@@ -95,10 +95,9 @@ def requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_f
     return m.astype(np.int32), (e | (k << 8)).astype(np.int32)
 
 
-def tables_are_fast(m, ek, vbits, allow_shift=False) -> bool:
+def tables_are_fast(m, ek, vbits, allow_shift=True) -> bool:
     """True if a (m, ek) table satisfies the conv kernels' fast contract for inputs |v| < 2^vbits:
-    e in [33, 62], k == 0 (unless ``allow_shift``: the scalar identity table, whose shift is applied
-    while unpacking the residual), and no exact rounding tie is possible.  A tie needs
+    e in [33, 62], vbits + k <= 31, and no exact rounding tie is possible.  A tie needs
     2^(e-1) | (v << k) * m, i.e. tz(v) >= e - 1 - k - tz(m); that exceeds every non-zero
     |v| < 2^vbits iff tz(m) <= e - 1 - k - vbits  (m == 0 gives 0 on both paths)."""
     m = np.asarray(m, np.int64).reshape(-1)
@@ -107,7 +106,7 @@ def tables_are_fast(m, ek, vbits, allow_shift=False) -> bool:
     vb = np.broadcast_to(np.asarray(vbits, np.int64), m.shape)
     if ((e < 33) | (e > 62)).any():
         return False
-    if (k != 0).any() and not allow_shift:
+    if ((k != 0).any() and not allow_shift) or (vb + k > 31).any():
         return False
     tz = np.array([((int(x) & -int(x)).bit_length() - 1) if x else 0 for x in m], np.int64)
     return bool(((m == 0) | (tz <= e - 1 - k - vb)).all())

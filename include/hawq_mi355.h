@@ -96,10 +96,10 @@ typedef struct hawq_conv_args {
     int32_t ldo, n_valid;
     int32_t *flags;       /* device int32: bit0 = uint16 residual overflow                     */
     int32_t tile;         /* 0 = heuristic; else tile config id (see hawq_conv2d_num_tiles)    */
-    const int32_t *ctab;    /* fast path only: [Cout][4] = {m, e-32, lo32(C), hi32(C)}, C = bias*m + 2^(e-1) */
+    const int32_t *ctab;    /* fast path only: [Cout][4] = {m, (e-32)|k<<8, lo32(C), hi32(C)}, C = (bias<<k)*m + 2^(e-1) */
     const int32_t *ctab_id; /* fast path, second branch: same for (bias2, m_id, e_id)                   */
     int32_t fast_tables;  /* caller asserts the "fast contract" for EVERY dyadic table of this call:
-                             e in [33,62]; k == 0 in per-channel tables and in (mq,eq); no exact
+                             e in [33,62]; |value << k| < 2^31; no exact
                              rounding tie is possible for the value ranges involved (the host proves
                              this from the trailing zeros of m - hawq_amd.quant_utils.tables_are_fast).
                              Enables the 2-instruction requant path and the LDS-staged coalesced

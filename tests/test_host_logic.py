@@ -47,8 +47,8 @@ def test_requant_table_matches_oracle_and_lifts_exactly():
     # tie-freeness proof: a power-of-two ratio can tie, a generic one cannot for narrow inputs
     assert not tables_are_fast(np.array([1 << 30]), np.array([34]), 20)
     assert tables_are_fast(np.array([(1 << 30) + 1]), np.array([40]), 24)
-    assert not tables_are_fast(np.array([(1 << 30) + 1]), np.array([33 | (1 << 8)]), 24)
-    assert tables_are_fast(np.array([(1 << 30) + 1]), np.array([33 | (1 << 8)]), 24, allow_shift=True)
+    assert tables_are_fast(np.array([(1 << 30) + 1]), np.array([33 | (1 << 8)]), 24)
+    assert not tables_are_fast(np.array([(1 << 30) + 1]), np.array([33 | (8 << 8)]), 24)  # 24 + 8 > 31 bits
 
 
 def test_tie_free_proof_is_sound_by_brute_force():
