@@ -169,6 +169,12 @@ def main():
         alg = roofline.algorithmic_bytes(args.arch, args.scheme, args.batch)
         macs = roofline.macs(args.arch, args.scheme, args.batch)
         gbs = alg / (gpu_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes (cannot be collected in-process)
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(f"{args.arch}_{args.scheme}_b{args.batch}", {}).get("bytes_per_launch")
+        except OSError:
+            pass
         out = {
             "metric": "images/sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -179,7 +185,7 @@ def main():
                        "residual_uint16_overflow": overflow,
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}"},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "one hipGraph launch = whole forward of one batch",
                          "gpu_ms_per_launch": round(gpu_ms, 4), "algorithmic_bytes_per_launch": alg,
                          "mfma_frac": round(2 * macs / (gpu_ms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)},
