@@ -44,14 +44,16 @@ struct ConvP {
     const int32_t *ctab, *ctab_id;
 };
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int NS_>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NS = NS_;           // LDS ring stages of the asynchronous (global_load_lds) pipeline
     static constexpr int PT = BM / WM / 32;  // pixel MFMA tiles per wave
     static constexpr int CT = BN / WN / 32;  // channel MFMA tiles per wave
     static constexpr int AL = BM / 64;       // 16-B A loads per thread per chunk
     static constexpr int WL = BN / 64;
-    static constexpr int LDS_BYTES = 2 * (BM + BN) * 64;
+    static constexpr int STAGE_BYTES = (BM + BN) * 64;
+    static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // the register-staged path uses the first two stages
     static_assert(WM * WN == 4, "4 waves per workgroup");
 };
 
@@ -210,6 +212,157 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[c][p][r] >>= 4;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Asynchronous int8 x int8 pipeline: both operand tiles of every K chunk are streamed
+// global -> LDS with global_load_lds (no VGPR staging, no ds_write) into an NS-stage ring, NS-1
+// chunks ahead of the MFMAs.  One s_barrier per chunk: [wait chunk k landed] [barrier: everyone is
+// also done reading the stage chunk k+NS-1 will overwrite] [issue chunk k+NS-1] [MFMA chunk k].
+// The LDS image is lane-linear (16 rows x 64 B per wave instruction), so the XOR swizzle that keeps
+// the fragment reads conflict-free is applied to the per-lane SOURCE address; padding taps and
+// rows beyond M read a 16-byte zero page.  With a second branch (identity conv) its chunks simply
+// continue the same chunk sequence and accumulate into acc2, so its loads overlap the first
+// branch's MFMAs.
+__device__ __attribute__((aligned(16))) const int g_zero16[4] = {0, 0, 0, 0};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <class C, bool DUAL>
+__device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1],
+                                                const ConvP &p, int m0, int c0, char *smem) {
+    constexpr int NS = C::NS, L = C::AL + C::WL, STAGE = C::STAGE_BYTES;
+    static_assert(2 * L <= 60, "vmcnt range");
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
+    const int lrow = t >> 2, lslot = t & 3;
+    const char *zero = reinterpret_cast<const char *>(g_zero16);
+
+    // im2col bookkeeping of this thread's rows (first branch) and of the second branch's 1x1/stride-s2 rows
+    int pix_base[C::AL], iy0[C::AL], ix0[C::AL], pix2[DUAL ? C::AL : 1];
+    bool mval[C::AL];
+    int asw[C::AL];  // source slot (16-B unit) after the swizzle
+#pragma unroll
+    for (int i = 0; i < C::AL; ++i) {
+        const int row = lrow + 64 * i;
+        const int m = m0 + row;
+        mval[i] = m < p.M;
+        const int mm = mval[i] ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int r = mm - n * (p.Ho * p.Wo);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        iy0[i] = oy * p.stride - p.pad;
+        ix0[i] = ox * p.stride - p.pad;
+        pix_base[i] = (n * p.H + iy0[i]) * p.W + ix0[i];
+        if (DUAL) pix2[DUAL ? i : 0] = (n * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2;
+        asw[i] = (lslot ^ ((row >> 2) & 3)) << 4;
+    }
+    int wsw[C::WL];
+#pragma unroll
+    for (int j = 0; j < C::WL; ++j) wsw[j] = (lslot ^ (((lrow + 64 * j) >> 2) & 3)) << 4;
+
+    const int taps = p.KH * p.KW, cch1 = p.Cin >> 6;
+    const int nk1 = taps * cch1, nk2 = DUAL ? (p.Cin2 >> 6) : 0, nk = nk1 + nk2;
+    const size_t wrow1 = (size_t)taps * p.Cin, wrow2 = DUAL ? (size_t)p.Cin2 : 0;
+
+    int kh = 0, kw = 0, cc = 0, jissue = 0, istage = 0;  // coordinates of the next chunk to ISSUE
+    auto issue = [&]() {
+        char *sa = smem + istage * STAGE + wave * 1024;  // + i * 4096: 64 rows x 64 B per pass
+        char *sw = smem + istage * STAGE + C::BM * 64 + wave * 1024;
+        if (!DUAL || jissue < nk1) {
+            const int tap_off = kh * p.W + kw;
+#pragma unroll
+            for (int i = 0; i < C::AL; ++i) {
+                const int iy = iy0[i] + kh, ix = ix0[i] + kw;
+                const bool v = mval[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const char *src = v ? (const char *)p.in + (size_t)(pix_base[i] + tap_off) * p.Cin + (cc << 6) + asw[i] : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sa + i * 4096), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < C::WL; ++j) {
+                const char *src = (const char *)p.wgt + (size_t)(c0 + lrow + 64 * j) * wrow1 +
+                                  (size_t)((kh * p.KW + kw) * p.Cin + (cc << 6)) + wsw[j];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sw + j * 4096), 16, 0, 0);
+            }
+            if (++cc == cch1) {
+                cc = 0;
+                if (++kw == p.KW) {
+                    kw = 0;
+                    ++kh;
+                }
+            }
+        } else {
+            const int c2 = jissue - nk1;
+#pragma unroll
+            for (int i = 0; i < C::AL; ++i) {
+                const char *src = mval[i] ? (const char *)p.in2 + (size_t)pix2[DUAL ? i : 0] * p.Cin2 + (c2 << 6) + asw[i] : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sa + i * 4096), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < C::WL; ++j) {
+                const char *src = (const char *)p.wgt2 + (size_t)(c0 + lrow + 64 * j) * wrow2 + (size_t)(c2 << 6) + wsw[j];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sw + j * 4096), 16, 0, 0);
+            }
+        }
+        ++jissue;
+        if (++istage == NS) istage = 0;
+    };
+
+    const int l31 = lane & 31, h = lane >> 5;
+    int arow[C::PT], wrow[C::CT];
+#pragma unroll
+    for (int q = 0; q < C::PT; ++q) arow[q] = wave_m * (C::PT * 32) + q * 32 + l31;
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) wrow[c] = wave_c * (C::CT * 32) + c * 32 + cperm(l31);
+
+    auto compute = [&](auto &a, int stage) {
+        const char *ldsA = smem + stage * STAGE, *ldsW = ldsA + C::BM * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = 2 * ks + h;
+            v4i wf[C::CT], af[C::PT];
+#pragma unroll
+            for (int c = 0; c < C::CT; ++c) wf[c] = *reinterpret_cast<const v4i *>(ldsW + lds_off(wrow[c], slot));
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q) af[q] = *reinterpret_cast<const v4i *>(ldsA + lds_off(arow[q], slot));
+#pragma unroll
+            for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+                for (int q = 0; q < C::PT; ++q)
+                    a[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[c], af[q], a[c][q], 0, 0, 0);
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+        if (j < nk) issue();
+    int cstage = 0;
+    auto step = [&](auto &a, int k) {
+        // chunk k must have landed: at most min(NS-2, chunks issued after k) chunks may stay in flight
+        const int after = min(NS - 2, nk - 1 - k);
+        if (after >= 2)
+            wait_vmcnt<2 * L>();
+        else if (after == 1)
+            wait_vmcnt<L>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (jissue < nk) issue();
+        compute(a, cstage);
+        if (++cstage == NS) cstage = 0;
+    };
+    for (int k = 0; k < nk1; ++k) step(acc, k);
+    if constexpr (DUAL)
+        for (int k = nk1; k < nk; ++k) step(acc2, k);
+    __syncthreads();  // all MFMA fragment reads done: the ring may be reused by the epilogue
 }
 
 // BITS: 0 = decide at run time (generic kernels), else (a_bits << 4) | w_bits.
@@ -541,8 +694,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
         for (int q = 0; q < C::PT; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
-    run_segment<C, BITS>(acc, p.in, p.wgt, p.in_bits, p.w_bits, p.H, p.W, p.Cin, p.KH, p.KW, p.stride, p.pad, p.Ho,
-                         p.Wo, p.M, p.Cout, m0, c0, smem);
     v16i acc2[DUAL ? C::CT : 1][DUAL ? C::PT : 1];
     if constexpr (DUAL) {
 #pragma unroll
@@ -551,8 +702,16 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
             for (int q = 0; q < C::PT; ++q)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[c][q][r] = 0;
-        run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2, 0,
-                              p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
+    }
+    constexpr bool ASYNC = BITS == 0x88 && (!DUAL || BITS2 == 0x88);
+    if constexpr (ASYNC) {
+        gemm_pipeline88<C, DUAL>(acc, acc2, p, m0, c0, smem);
+    } else {
+        run_segment<C, BITS>(acc, p.in, p.wgt, p.in_bits, p.w_bits, p.H, p.W, p.Cin, p.KH, p.KW, p.stride, p.pad,
+                             p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
+        if constexpr (DUAL)
+            run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2,
+                                  0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
     }
     if constexpr (FAST)
         epilogue_fast<C, EPI, DUAL>(p, acc, acc2, m0, c0, smem, res_tile);
@@ -560,10 +719,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
 
-using T0 = Cfg<128, 128, 2, 2>;
-using T1 = Cfg<256, 64, 4, 1>;
-using T2 = Cfg<64, 64, 2, 2>;
-using T3 = Cfg<128, 64, 2, 2>;
+using T0 = Cfg<128, 128, 2, 2, 3>;
+using T1 = Cfg<256, 64, 4, 1, 3>;
+using T2 = Cfg<64, 64, 2, 2, 4>;
+using T3 = Cfg<128, 64, 2, 2, 4>;
 constexpr int NUM_TILES = 4;
 
 typedef void (*KernelFn)(const ConvP);
