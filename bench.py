@@ -183,14 +183,15 @@ def main():
                        "scheme": args.scheme, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
                        "residual_uint16_overflow": overflow,
-                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}"},
+                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}",
+                       "autotuned_tiles": "".join(str(t) for t in eng.tile_choice.values())},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "one hipGraph launch = whole forward of one batch",
                          "gpu_ms_per_launch": round(gpu_ms, 4), "algorithmic_bytes_per_launch": alg,
                          "mfma_frac": round(2 * macs / (gpu_ms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)},
         }
-        if not args.no_extra and world == 1:
+        if (not args.no_extra or args.per_op) and world == 1:
             ops = eng.profile_ops()
             tot = sum(ms for _, ms in ops)
             rows = {r["name"]: r for r in roofline.layer_table(args.arch, args.scheme)}

@@ -15,6 +15,8 @@
 //
 // Reference arithmetic replaced: quant_modules.py:489-494 (conv), q_resnet.py:242-258 (ReLU,
 // residual add), quant_utils.py:390-456 (fixedpoint_fn case 0 / case 1).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -42,6 +44,7 @@ struct ConvP {
     int ldo, n_valid;
     int32_t *flags;
     const int32_t *ctab, *ctab_id;
+    int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int NS_>
@@ -355,8 +358,8 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
         else
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (jissue < nk) issue();
-        compute(a, cstage);
+        if (jissue < nk && !(p.dbg & 1)) issue();
+        if (!(p.dbg & 2)) compute(a, cstage);
         if (++cstage == NS) cstage = 0;
     };
     for (int k = 0; k < nk1; ++k) step(acc, k);
@@ -527,7 +530,7 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
 template <class C, int EPI, bool DUAL>
 __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
                                               v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
-                                              char *q_tile, char *res_tile) {
+                                              char *q_tile, char *res_tile, const char *ctab_lds) {
     using S = Stage<C>;
     constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -539,7 +542,6 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
         const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;  // tile-local first channel of this lane
-        const int ch = c0 + lch;
         v4i rin[C::PT][2];
         if constexpr (RES && !DUAL) {
 #pragma unroll
@@ -563,11 +565,11 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
             DyNt dm[4], di[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const v4i t = ld4(p.ctab + (ch + 4 * g + j) * 4);
+                const v4i t = *reinterpret_cast<const v4i *>(ctab_lds + (lch + 4 * g + j) * 16);
                 dm[j].m = t.x, dm[j].s = t.y & 0xff, dm[j].k = t.y >> 8;
                 dm[j].add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
                 if constexpr (DUAL) {
-                    const v4i u = ld4(p.ctab_id + (ch + 4 * g + j) * 4);
+                    const v4i u = *reinterpret_cast<const v4i *>(ctab_lds + C::BN * 16 + (lch + 4 * g + j) * 16);
                     di[j].m = u.x, di[j].s = u.y & 0xff, di[j].k = u.y >> 8;
                     di[j].add = (long long)(((unsigned long long)(unsigned)u.w << 32) | (unsigned)u.z);
                 } else {
@@ -636,7 +638,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
         }
         }  // qp
     }
-    if (RES && (oor >> 16) != 0 && p.res_out) atomicOr(p.flags, 1);  // rows beyond M never reach memory but may flag: harmless
+    if (RES && (oor >> 16) != 0 && p.res_out && !p.dbg) atomicOr(p.flags, 1);
+    if (p.dbg & 8) return;  // rows beyond M never reach memory but may flag: harmless
     __syncthreads();
     const int t = threadIdx.x;
     if constexpr (RES) {
@@ -685,6 +688,20 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
     const int m0 = tm * C::BM, c0 = tc * C::BN;
     constexpr bool FAST = BITS != 0 && (EPI == HAWQ_EPI_REQUANT || EPI == HAWQ_EPI_RESIDUAL);
     char *res_tile = smem + C::LDS_BYTES;
+    char *ctab_lds = res_tile + (EPI == HAWQ_EPI_RESIDUAL ? C::BM * C::BN * 2 : 0);  // [BN][16 B] (+ second branch)
+    if constexpr (FAST) {
+        // the per-channel requant constants of this tile go to LDS asynchronously, off the epilogue's critical path
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (wave < C::BN / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.ctab + (size_t)(c0 + wave * 64 + lane) * 4),
+                                             (__attribute__((address_space(3))) void *)(ctab_lds + wave * 1024), 16, 0, 0);
+        if constexpr (DUAL) {
+            if (wave >= 2 && wave - 2 < C::BN / 64)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(p.ctab_id + (size_t)(c0 + (wave - 2) * 64 + lane) * 4),
+                    (__attribute__((address_space(3))) void *)(ctab_lds + C::BN * 16 + (wave - 2) * 1024), 16, 0, 0);
+        }
+    }
     if constexpr (FAST && EPI == HAWQ_EPI_RESIDUAL && !DUAL) prefetch_residual<C>(p, m0, c0, res_tile);
 
     v16i acc[C::CT][C::PT];
@@ -713,8 +730,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
             run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2,
                                   0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
     }
+    if (p.dbg & 4) return;
     if constexpr (FAST)
-        epilogue_fast<C, EPI, DUAL>(p, acc, acc2, m0, c0, smem, res_tile);
+        epilogue_fast<C, EPI, DUAL>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
     else
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
@@ -753,7 +771,7 @@ const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0), TILE_ENTRY(T1), TILE_ENTRY(T
 bool raise_lds_limits() {
     bool ok = true;
     for (const TileInfo &ti : kTiles) {
-        const int lds = ti.lds + ti.BM * ti.BN * 2;
+        const int lds = ti.lds + ti.BM * ti.BN * 2 + ti.BN * 32;
         if (lds <= 64 * 1024) continue;
         for (int v = 1; v < 3; ++v)
             ok &= hipFuncSetAttribute((const void *)ti.single[2][v], hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
@@ -825,6 +843,8 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
     p.flags = a->flags;
     p.ctab = a->ctab, p.ctab_id = a->ctab_id;
+    static const int dbg_env = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
+    p.dbg = dbg_env;
     const bool fast = a->fast_tables != 0;
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
@@ -896,11 +916,12 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (dual) {
         const int v1 = variant(p.in_bits, p.w_bits), v2 = variant(p.in2_bits, p.w2_bits);
         fn = (v1 == 0 || v2 == 0) ? ti.dual[0] : ti.dual[v1 == v2 ? v1 : (v1 == 1 ? 3 : 4)];
-        if (v1 != 0 && v2 != 0) lds += ti.BM * ti.BN * 2;
+        if (v1 != 0 && v2 != 0) lds += ti.BM * ti.BN * 2 + ti.BN * 32;
     } else {
         const int v = variant(p.in_bits, p.w_bits);
         fn = ti.single[slot][v];
         if (v != 0 && slot == 2) lds += ti.BM * ti.BN * 2;
+        if (v != 0 && needs_tables) lds += ti.BN * 16;
     }
     static const bool attrs_ok = raise_lds_limits();  // once per process; never inside a capture
     HAWQ_REQUIRE(attrs_ok, "hawq_conv2d: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

@@ -94,7 +94,7 @@ class IntegerEngine:
     instead of re-deriving them from the float parameters."""
 
     def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
-                 keep_accumulators: bool = False, fast: bool = True):
+                 keep_accumulators: bool = False, fast: bool = True, autotune: bool = True):
         if not model.is_frozen():
             raise RuntimeError("IntegerEngine needs a frozen model (freeze_model) - ranges must be fixed")
         _lib.load()
@@ -107,6 +107,8 @@ class IntegerEngine:
         self.use_graph = use_graph
         self.keep_acc = keep_accumulators
         self.fast = fast  # False forces the exact general kernels everywhere (reference for tests)
+        self.autotune = autotune  # pick each conv launch's tile configuration by timing it once per batch shape
+        self.tile_choice = {}
         self.stream = torch.cuda.Stream(device=self.dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._batch = None
@@ -233,6 +235,7 @@ class IntegerEngine:
         """Allocate activation buffers for batch N and record the launch list."""
         P, dev = self.P, self.dev
         ops, keep = _OpList(), []
+        self._conv_args, self._conv_names = [], []
         self.acc_taps = {}
         self.n_fast = self.n_conv = 0  # how many conv launches run the fast-contract kernels
         sp = self.stream.cuda_stream
@@ -320,6 +323,8 @@ class IntegerEngine:
                     if ci == len(u['convs']) - 1 and u['resize']:
                         self._add_ident_tap(ops, keep, u, qa, N, h, w, ho, wo)
                 keep.append(a)
+                self._conv_args.append(a)
+                self._conv_names.append(tap_name)
                 ops.next_name = tap_name + ("+identity" if (a.in2 is not None) else "")
                 ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
                 if ci < len(u['convs']) - 1:
@@ -351,6 +356,8 @@ class IntegerEngine:
         keep += [qf, pooled, a]
         self._ops, self._keep, self._batch = ops, keep, (N, H, W)
         self._graph = None
+        if self.autotune and not self.keep_acc:
+            self._autotune_tiles()
 
     def _add_acc_tap(self, ops, keep, a, name, N, ho, wo, cout):
         """Extra RAW launch of the same conv to expose its int32 accumulators (tests only)."""
@@ -374,6 +381,41 @@ class IntegerEngine:
         keep += [acc, r]
         self.acc_taps[u['name'] + ".quant_identity_convbn"] = (acc, (N, ho, wo, ic.cout))
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
+
+    def _autotune_tiles(self, reps: int = 3):
+        """Time every conv launch with each tile configuration (HIP events on the engine stream, the
+        real buffers, results are identical for every tile) and keep the fastest.  Runs once per batch
+        shape, before the hipGraph is captured: ~50 launches x 4 tiles x reps, a few milliseconds."""
+        n_tiles = _lib.load().hawq_conv2d_num_tiles()
+        sp = self.stream.cuda_stream
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.call("hawq_event_create", C.byref(e0))
+        _lib.call("hawq_event_create", C.byref(e1))
+        ms = C.c_float()
+        with torch.cuda.stream(self.stream):
+            self._launch_all()  # every buffer holds valid data
+            for name, a in [(n, k) for n, k in zip(self._conv_names, self._conv_args)]:
+                if os.environ.get("HAWQ_TILE_RES") or os.environ.get("HAWQ_TILE_REQ"):
+                    break
+                best, best_t = None, 0
+                for tile in range(1, n_tiles + 1):
+                    a.tile = tile
+                    try:
+                        _lib.call("hawq_conv2d", C.byref(a), sp)  # warm
+                        _lib.call("hawq_event_record", e0, sp)
+                        for _ in range(reps):
+                            _lib.call("hawq_conv2d", C.byref(a), sp)
+                        _lib.call("hawq_event_record", e1, sp)
+                        _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
+                    except RuntimeError:
+                        continue
+                    if best is None or ms.value < best:
+                        best, best_t = ms.value, tile
+                a.tile = best_t
+                self.tile_choice[name] = best_t
+        _lib.call("hawq_event_destroy", e0)
+        _lib.call("hawq_event_destroy", e1)
+        torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ execution
     def _launch_all(self):
