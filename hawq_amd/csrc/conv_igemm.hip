@@ -47,15 +47,16 @@ struct ConvP {
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
 };
 
-template <int BM_, int BN_, int WM_, int WN_, int NS_>
+template <int BM_, int BN_, int WM_, int WN_, int NS_, int KSUB_ = 1>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr int NS = NS_;           // LDS ring stages of the asynchronous (global_load_lds) pipeline
+    static constexpr int KSUB = KSUB_;       // 64-channel sub-chunks per ring stage (one barrier per stage)
     static constexpr int PT = BM / WM / 32;  // pixel MFMA tiles per wave
     static constexpr int CT = BN / WN / 32;  // channel MFMA tiles per wave
     static constexpr int AL = BM / 64;       // 16-B A loads per thread per chunk
     static constexpr int WL = BN / 64;
-    static constexpr int STAGE_BYTES = (BM + BN) * 64;
+    static constexpr int STAGE_BYTES = KSUB * (BM + BN) * 64;
     static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // the register-staged path uses the first two stages
     static_assert(WM * WN == 4, "4 waves per workgroup");
 };
@@ -238,7 +239,7 @@ template <class C, bool DUAL>
 __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1],
                                                 const ConvP &p, int m0, int c0, char *smem) {
     constexpr int NS = C::NS, L = C::AL + C::WL, STAGE = C::STAGE_BYTES;
-    static_assert(2 * L <= 60, "vmcnt range");
+    static_assert((NS - 2) * L * C::KSUB <= 60, "vmcnt range");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wave_m = wave % C::WM, wave_c = wave / C::WM;
@@ -272,10 +273,11 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     const int nk1 = taps * cch1, nk2 = DUAL ? (p.Cin2 >> 6) : 0, nk = nk1 + nk2;
     const size_t wrow1 = (size_t)taps * p.Cin, wrow2 = DUAL ? (size_t)p.Cin2 : 0;
 
-    int kh = 0, kw = 0, cc = 0, jissue = 0, istage = 0;  // coordinates of the next chunk to ISSUE
-    auto issue = [&]() {
-        char *sa = smem + istage * STAGE + wave * 1024;  // + i * 4096: 64 rows x 64 B per pass
-        char *sw = smem + istage * STAGE + C::BM * 64 + wave * 1024;
+    constexpr int KSUB = C::KSUB, SUBB = (C::BM + C::BN) * 64;  // bytes of one 64-channel sub-chunk (A rows, then W rows)
+    int kh = 0, kw = 0, cc = 0, jissue = 0, istage = 0;  // coordinates of the next sub-chunk to ISSUE
+    auto issue_sub = [&](int sub) {
+        char *sa = smem + istage * STAGE + sub * SUBB + wave * 1024;  // + i * 4096: 64 rows x 64 B per pass
+        char *sw = sa + C::BM * 64;
         if (!DUAL || jissue < nk1) {
             const int tap_off = kh * p.W + kw;
 #pragma unroll
@@ -316,6 +318,10 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
             }
         }
         ++jissue;
+    };
+    auto issue = [&]() {  // one ring stage = KSUB consecutive sub-chunks (nk1 and nk2 are multiples of KSUB)
+#pragma unroll
+        for (int sub = 0; sub < KSUB; ++sub) issue_sub(sub);
         if (++istage == NS) istage = 0;
     };
 
@@ -327,44 +333,57 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     for (int c = 0; c < C::CT; ++c) wrow[c] = wave_c * (C::CT * 32) + c * 32 + cperm(l31);
 
     auto compute = [&](auto &a, int stage) {
-        const char *ldsA = smem + stage * STAGE, *ldsW = ldsA + C::BM * 64;
+        // fragments of K-step s+1 are fetched from LDS while the MFMAs of K-step s run
+        v4i wf[2][C::CT], af[2][C::PT];
+        auto fetch = [&](int s, int buf) {
+            const char *ldsA = smem + stage * STAGE + (s >> 1) * SUBB, *ldsW = ldsA + C::BM * 64;
+            const int slot = 2 * (s & 1) + h;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = 2 * ks + h;
-            v4i wf[C::CT], af[C::PT];
+            for (int c = 0; c < C::CT; ++c) wf[buf][c] = *reinterpret_cast<const v4i *>(ldsW + lds_off(wrow[c], slot));
 #pragma unroll
-            for (int c = 0; c < C::CT; ++c) wf[c] = *reinterpret_cast<const v4i *>(ldsW + lds_off(wrow[c], slot));
+            for (int q = 0; q < C::PT; ++q) af[buf][q] = *reinterpret_cast<const v4i *>(ldsA + lds_off(arow[q], slot));
+        };
+        fetch(0, 0);
 #pragma unroll
-            for (int q = 0; q < C::PT; ++q) af[q] = *reinterpret_cast<const v4i *>(ldsA + lds_off(arow[q], slot));
+        for (int s = 0; s < 2 * KSUB; ++s) {
+            if (s + 1 < 2 * KSUB) fetch(s + 1, (s + 1) & 1);
 #pragma unroll
             for (int c = 0; c < C::CT; ++c)
 #pragma unroll
                 for (int q = 0; q < C::PT; ++q)
-                    a[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[c], af[q], a[c][q], 0, 0, 0);
+                    a[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s & 1][c], af[s & 1][q], a[c][q], 0, 0, 0);
         }
     };
 
+    const int ns1 = nk1 / KSUB, nst = nk / KSUB;  // ring stages of the first branch / in total
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j)
-        if (j < nk) issue();
+        if (j < nst) issue();
     int cstage = 0;
+    constexpr int LS = L * KSUB;  // loads per thread per stage
     auto step = [&](auto &a, int k) {
-        // chunk k must have landed: at most min(NS-2, chunks issued after k) chunks may stay in flight
-        const int after = min(NS - 2, nk - 1 - k);
-        if (after >= 2)
-            wait_vmcnt<2 * L>();
-        else if (after == 1)
-            wait_vmcnt<L>();
-        else
-            wait_vmcnt<0>();
+        // stage k must have landed: at most min(NS-2, stages issued after k) stages may stay in flight
+        const int after = min(NS - 2, nst - 1 - k);
+        if (after >= NS - 2) {
+            wait_vmcnt<(NS - 2) * LS>();  // steady state
+        } else {  // tail: fewer stages behind stage k, wait for exactly those to remain
+            switch (after) {
+                case 5: wait_vmcnt<(NS > 6 ? 5 : 0) * LS>(); break;
+                case 4: wait_vmcnt<(NS > 5 ? 4 : 0) * LS>(); break;
+                case 3: wait_vmcnt<(NS > 4 ? 3 : 0) * LS>(); break;
+                case 2: wait_vmcnt<(NS > 3 ? 2 : 0) * LS>(); break;
+                case 1: wait_vmcnt<(NS > 2 ? 1 : 0) * LS>(); break;
+                default: wait_vmcnt<0>(); break;
+            }
+        }
         __builtin_amdgcn_s_barrier();
         if (jissue < nk && !(p.dbg & 1)) issue();
         if (!(p.dbg & 2)) compute(a, cstage);
         if (++cstage == NS) cstage = 0;
     };
-    for (int k = 0; k < nk1; ++k) step(acc, k);
+    for (int k = 0; k < ns1; ++k) step(acc, k);
     if constexpr (DUAL)
-        for (int k = nk1; k < nk; ++k) step(acc2, k);
+        for (int k = ns1; k < nst; ++k) step(acc2, k);
     __syncthreads();  // all MFMA fragment reads done: the ring may be reused by the epilogue
 }
 
@@ -741,21 +760,26 @@ using T0 = Cfg<128, 128, 2, 2, 3>;
 using T1 = Cfg<256, 64, 4, 1, 3>;
 using T2 = Cfg<64, 64, 2, 2, 4>;
 using T3 = Cfg<128, 64, 2, 2, 4>;
-constexpr int NUM_TILES = 4;
+// two sub-chunks (K = 128) per ring stage and barrier for the long-K / few-workgroup layers (stages 3-4);
+// need an even chunk count, otherwise the launcher falls back to the single-sub-chunk twin
+using T4 = Cfg<128, 128, 2, 2, 3, 2>;  // K = 128 per barrier
+using T5 = Cfg<64, 64, 2, 2, 4, 2>;
+using T6 = Cfg<128, 64, 2, 2, 3, 2>;
+constexpr int NUM_TILES = 7;
 
 typedef void (*KernelFn)(const ConvP);
 // single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
 // dual-branch (RESIDUAL + identity conv): {run-time, 88/88, 44/44, 88/44, 44/88}
 struct TileInfo {
-    int BM, BN, lds;
+    int BM, BN, lds, ksub, twin;  // twin: tile id with the same BM x BN and KSUB == 1
     KernelFn single[4][3];
     KernelFn dual[5];
 };
 #define SINGLE_ROW(T, E) \
     { conv_kernel<T, E, false, 0, 0>, conv_kernel<T, E, false, 0x88, 0>, conv_kernel<T, E, false, 0x44, 0> }
-#define TILE_ENTRY(T)                                                                                          \
+#define TILE_ENTRY(T, TWIN)                                                                                          \
     {                                                                                                          \
-        T::BM, T::BN, T::LDS_BYTES,                                                                            \
+        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN,                                                             \
             {SINGLE_ROW(T, HAWQ_EPI_RAW), SINGLE_ROW(T, HAWQ_EPI_REQUANT), SINGLE_ROW(T, HAWQ_EPI_RESIDUAL),   \
              SINGLE_ROW(T, HAWQ_EPI_DEQUANT)},                                                                 \
         {                                                                                                      \
@@ -765,7 +789,8 @@ struct TileInfo {
                 conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x44, 0x88>                                            \
         }                                                                                                      \
     }
-const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0), TILE_ENTRY(T1), TILE_ENTRY(T2), TILE_ENTRY(T3)};
+const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0, 0), TILE_ENTRY(T1, 1), TILE_ENTRY(T2, 2), TILE_ENTRY(T3, 3),
+                                    TILE_ENTRY(T4, 0), TILE_ENTRY(T5, 2), TILE_ENTRY(T6, 3)};
 
 // kernels whose staged epilogue needs more than the default 64 KiB of dynamic LDS
 bool raise_lds_limits() {
@@ -844,7 +869,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.flags = a->flags;
     p.ctab = a->ctab, p.ctab_id = a->ctab_id;
     static const int dbg_env = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
-    p.dbg = dbg_env;
+    p.dbg = a->fast_tables ? dbg_env : 0;  // ablations only touch the fused-plan launches
     const bool fast = a->fast_tables != 0;
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
@@ -901,6 +926,11 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
     HAWQ_REQUIRE(tile >= 0 && tile < NUM_TILES, "hawq_conv2d: bad tile id %d", a->tile);
     if (p.Cout % kTiles[tile].BN != 0) tile = 2;
+    if (kTiles[tile].ksub > 1) {  // K = 128 per barrier: int8 x int8 async pipeline with even chunk counts only
+        const int nk1 = a->KH * a->KW * (a->Cin >> 6), nk2 = dual ? (a->Cin2 >> 6) : 0;
+        const bool all88 = a->in_bits == 8 && a->w_bits == 8 && (!dual || (a->in2_bits == 8 && a->w2_bits == 8));
+        if (!all88 || (nk1 % kTiles[tile].ksub) || (nk2 % kTiles[tile].ksub)) tile = kTiles[tile].twin;
+    }
     const TileInfo &ti = kTiles[tile];
     const int grid = ((p.M + ti.BM - 1) / ti.BM) * (p.Cout / ti.BN);
     // 32-bit residual tensors use the generic (run-time bit-width, direct epilogue) kernels

@@ -94,7 +94,17 @@ class IntegerEngine:
     instead of re-deriving them from the float parameters."""
 
     def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
-                 keep_accumulators: bool = False, fast: bool = True, autotune: bool = True):
+                 keep_accumulators: bool = False, fast: bool = True, autotune: bool = True, chains: int = 1,
+                 _parent=None):
+        if _parent is not None:  # a chain of a multi-chain engine: shares parameters, owns stream + buffers
+            self.__dict__.update({k: v for k, v in _parent.__dict__.items()
+                                  if k in ("model", "dev", "res_bits", "from_buffers", "keep_acc", "fast", "autotune",
+                                           "flags", "P")})
+            self.use_graph, self.chains, self.subs = False, 1, []
+            self.stream = torch.cuda.Stream(device=self.dev)
+            self.tile_choice = {}
+            self._batch = self._graph = None
+            return
         if not model.is_frozen():
             raise RuntimeError("IntegerEngine needs a frozen model (freeze_model) - ranges must be fixed")
         _lib.load()
@@ -109,6 +119,10 @@ class IntegerEngine:
         self.fast = fast  # False forces the exact general kernels everywhere (reference for tests)
         self.autotune = autotune  # pick each conv launch's tile configuration by timing it once per batch shape
         self.tile_choice = {}
+        # chains > 1: the batch is split into independent sub-batches whose launch chains run on separate
+        # streams inside ONE hipGraph, so that one chain's kernel tails / launch gaps overlap the other's work
+        self.chains = 1 if keep_accumulators else max(1, int(os.environ.get("HAWQ_CHAINS", chains)))
+        self.subs = []
         self.stream = torch.cuda.Stream(device=self.dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._batch = None
@@ -231,9 +245,24 @@ class IntegerEngine:
     def _alloc(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.dev)
 
-    def _build(self, N, H, W):
+    def _build(self, N, H, W, x_view=None, logits_view=None):
         """Allocate activation buffers for batch N and record the launch list."""
         P, dev = self.P, self.dev
+        if self.chains > 1 and N >= 2 * self.chains:
+            self.x_in = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
+            self.logits = torch.empty(N, P['fc']['nout'], dtype=torch.float32, device=dev)
+            self.subs, b0 = [], 0
+            for i in range(self.chains):
+                b1 = b0 + N // self.chains + (1 if i < N % self.chains else 0)
+                sub = IntegerEngine(None, _parent=self)
+                sub._build(b1 - b0, H, W, self.x_in[b0:b1], self.logits[b0:b1])
+                self.subs.append(sub)
+                b0 = b1
+            self._ops, self._keep, self._batch, self._graph = _OpList(), [], (N, H, W), None
+            self.n_fast, self.n_conv = self.subs[0].n_fast, self.subs[0].n_conv
+            self.tile_choice = self.subs[0].tile_choice
+            return
+        self.subs = []
         ops, keep = _OpList(), []
         self._conv_args, self._conv_names = [], []
         self.acc_taps = {}
@@ -241,7 +270,7 @@ class IntegerEngine:
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
         rdt = torch.uint16 if self.res_bits == 16 else torch.int32
-        self.x_in = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
+        self.x_in = x_view if x_view is not None else torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
         # stem
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         Hp, Wp = 2 * (Ho - 1) + 7 + 1, 2 * (Wo - 1) + 8
@@ -342,7 +371,7 @@ class IntegerEngine:
         fc = P['fc']
         if fc['k'] != cl:
             raise RuntimeError("FC input width does not match the last stage")
-        self.logits = torch.empty(N, fc['nout'], dtype=torch.float32, device=dev)
+        self.logits = logits_view if logits_view is not None else torch.empty(N, fc['nout'], dtype=torch.float32, device=dev)
         a = _lib.ConvArgs()
         a.in_, a.wgt, a.bias = qf.data_ptr(), fc['w'].data_ptr(), fc['bias'].data_ptr()
         a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = N, 1, 1, fc['k'], fc['nout_p'], 1, 1, 1, 0
@@ -419,6 +448,17 @@ class IntegerEngine:
 
     # ------------------------------------------------------------------ execution
     def _launch_all(self):
+        if self.subs:  # fork: every chain on its own stream, joined back into self.stream
+            fork = torch.cuda.Event()
+            fork.record(self.stream)
+            for sub in self.subs:
+                sub.stream.wait_event(fork)
+                for op in sub._ops:
+                    op()
+                join = torch.cuda.Event()
+                join.record(sub.stream)
+                self.stream.wait_event(join)
+            return
         for op in self._ops:
             op()
 
@@ -458,6 +498,8 @@ class IntegerEngine:
     def profile_ops(self, repeats: int = 5):
         """Per-launch durations (ms, median of ``repeats``) measured with HIP events around each
         eager launch on the engine stream.  Returns [(name, ms)] in launch order."""
+        if self.subs:
+            return self.subs[0].profile_ops(repeats)
         sp = self.stream.cuda_stream
         evs = []
         for _ in range(len(self._ops) + 1):
