@@ -52,13 +52,17 @@ struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr int NS = NS_;           // LDS ring stages of the asynchronous (global_load_lds) pipeline
     static constexpr int KSUB = KSUB_;       // 64-channel sub-chunks per ring stage (one barrier per stage)
+    static constexpr int NW = WM_ * WN_;     // waves per workgroup (4 or 8)
+    static constexpr int NT = NW * 64;       // threads per workgroup
+    static constexpr int RPP = NT / 4;       // operand rows staged per pass (4 lanes x 16 B per 64-B row)
     static constexpr int PT = BM / WM / 32;  // pixel MFMA tiles per wave
     static constexpr int CT = BN / WN / 32;  // channel MFMA tiles per wave
-    static constexpr int AL = BM / 64;       // 16-B A loads per thread per chunk
-    static constexpr int WL = BN / 64;
+    static constexpr int AL = BM / RPP;      // 16-B A loads per thread per chunk
+    static constexpr int WL = BN / RPP;
     static constexpr int STAGE_BYTES = KSUB * (BM + BN) * 64;
     static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // the register-staged path uses the first two stages
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must fill whole staging passes");
 };
 
 // MFMA C/D row i of a 32x32 tile lives in (reg, half) with i = (reg&3) + 8*(reg>>2) + 4*half.
@@ -116,7 +120,7 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
     bool mval[C::AL];
 #pragma unroll
     for (int i = 0; i < C::AL; ++i) {
-        const int m = m0 + lrow + 64 * i;
+        const int m = m0 + lrow + C::RPP * i;
         mval[i] = m < M;
         const int mm = mval[i] ? m : 0;
         const int n = mm / (Ho * Wo);
@@ -147,7 +151,7 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
         }
 #pragma unroll
         for (int j = 0; j < C::WL; ++j) {
-            const int c = c0 + lrow + 64 * j;
+            const int c = c0 + lrow + C::RPP * j;
             const bool v = c < Cout;
             const size_t off = (size_t)c * wrow_bytes + ((size_t)((kh * KW + kw) * Cin + (cc << 6))) * W_BITS / 8 +
                                lslot * WBYTES;
@@ -166,13 +170,13 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
         for (int i = 0; i < C::AL; ++i) {
             v4i v = ra[i];
             if (A_BITS == 4) v = unpack16<false>((unsigned)v.x, (unsigned)v.y);
-            *reinterpret_cast<v4i *>(ldsA + buf * C::BM * 64 + lds_off(lrow + 64 * i, lslot)) = v;
+            *reinterpret_cast<v4i *>(ldsA + buf * C::BM * 64 + lds_off(lrow + C::RPP * i, lslot)) = v;
         }
 #pragma unroll
         for (int j = 0; j < C::WL; ++j) {
             v4i v = rw[j];
             if (W_BITS == 4) v = unpack16<true>((unsigned)v.x, (unsigned)v.y);
-            *reinterpret_cast<v4i *>(ldsW + buf * C::BN * 64 + lds_off(lrow + 64 * j, lslot)) = v;
+            *reinterpret_cast<v4i *>(ldsW + buf * C::BN * 64 + lds_off(lrow + C::RPP * j, lslot)) = v;
         }
     };
 
@@ -252,7 +256,7 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     int asw[C::AL];  // source slot (16-B unit) after the swizzle
 #pragma unroll
     for (int i = 0; i < C::AL; ++i) {
-        const int row = lrow + 64 * i;
+        const int row = lrow + C::RPP * i;
         const int m = m0 + row;
         mval[i] = m < p.M;
         const int mm = mval[i] ? m : 0;
@@ -267,7 +271,7 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     }
     int wsw[C::WL];
 #pragma unroll
-    for (int j = 0; j < C::WL; ++j) wsw[j] = (lslot ^ (((lrow + 64 * j) >> 2) & 3)) << 4;
+    for (int j = 0; j < C::WL; ++j) wsw[j] = (lslot ^ (((lrow + C::RPP * j) >> 2) & 3)) << 4;
 
     const int taps = p.KH * p.KW, cch1 = p.Cin >> 6;
     const int nk1 = taps * cch1, nk2 = DUAL ? (p.Cin2 >> 6) : 0, nk = nk1 + nk2;
@@ -276,7 +280,7 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     constexpr int KSUB = C::KSUB, SUBB = (C::BM + C::BN) * 64;  // bytes of one 64-channel sub-chunk (A rows, then W rows)
     int kh = 0, kw = 0, cc = 0, jissue = 0, istage = 0;  // coordinates of the next sub-chunk to ISSUE
     auto issue_sub = [&](int sub) {
-        char *sa = smem + istage * STAGE + sub * SUBB + wave * 1024;  // + i * 4096: 64 rows x 64 B per pass
+        char *sa = smem + istage * STAGE + sub * SUBB + wave * 1024;  // + i * RPP * 64: RPP rows x 64 B per pass
         char *sw = sa + C::BM * 64;
         if (!DUAL || jissue < nk1) {
             const int tap_off = kh * p.W + kw;
@@ -286,14 +290,14 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
                 const bool v = mval[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const char *src = v ? (const char *)p.in + (size_t)(pix_base[i] + tap_off) * p.Cin + (cc << 6) + asw[i] : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sa + i * 4096), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(sa + i * (C::RPP * 64)), 16, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < C::WL; ++j) {
-                const char *src = (const char *)p.wgt + (size_t)(c0 + lrow + 64 * j) * wrow1 +
+                const char *src = (const char *)p.wgt + (size_t)(c0 + lrow + C::RPP * j) * wrow1 +
                                   (size_t)((kh * p.KW + kw) * p.Cin + (cc << 6)) + wsw[j];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sw + j * 4096), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(sw + j * (C::RPP * 64)), 16, 0, 0);
             }
             if (++cc == cch1) {
                 cc = 0;
@@ -308,13 +312,13 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
             for (int i = 0; i < C::AL; ++i) {
                 const char *src = mval[i] ? (const char *)p.in2 + (size_t)pix2[DUAL ? i : 0] * p.Cin2 + (c2 << 6) + asw[i] : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sa + i * 4096), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(sa + i * (C::RPP * 64)), 16, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < C::WL; ++j) {
-                const char *src = (const char *)p.wgt2 + (size_t)(c0 + lrow + 64 * j) * wrow2 + (size_t)(c2 << 6) + wsw[j];
+                const char *src = (const char *)p.wgt2 + (size_t)(c0 + lrow + C::RPP * j) * wrow2 + (size_t)(c2 << 6) + wsw[j];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sw + j * 4096), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(sw + j * (C::RPP * 64)), 16, 0, 0);
             }
         }
         ++jissue;
@@ -535,8 +539,8 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
     using S = Stage<C>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < C::BM * S::RCPR / 256; ++i) {
-        const int base = (i * 4 + wave) * 64;
+    for (int i = 0; i < C::BM * S::RCPR / C::NT; ++i) {
+        const int base = (i * C::NW + wave) * 64;
         const int idx = base + lane;
         const int row = idx / S::RCPR, j = idx % S::RCPR;
         const int grow = (m0 + row < p.M) ? m0 + row : m0;
@@ -558,6 +562,9 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     const int lrow0 = wave_m * (C::PT * 32) + l31;  // tile-local pixel row of pixel tile 0
     const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
     unsigned oor = 0;               // OR of all residual outputs: bits >= 16 set <=> uint16 overflow
+    unsigned rowmask[C::PT];
+#pragma unroll
+    for (int q = 0; q < C::PT; ++q) rowmask[q] = (m0 + lrow0 + q * 32 < p.M) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
         const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;  // tile-local first channel of this lane
@@ -621,7 +628,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                         o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
                         qv[j] = min(dyadic_nt(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
                     }
-                    oor |= (unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3]);
+                    // rows beyond M hold bias-only garbage: they never reach memory and must not raise the flag
+                    oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask[q];
                     rpack[qq][RES ? 2 * g : 0] = pack2_u16_sat(o[0], o[1]);
                     rpack[qq][RES ? 2 * g + 1 : 0] = pack2_u16_sat(o[2], o[3]);
                 }
@@ -664,8 +672,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     if constexpr (RES) {
         if (p.res_out) {
 #pragma unroll
-            for (int i = 0; i < C::BM * S::RCPR / 256; ++i) {
-                const int idx = t + 256 * i;
+            for (int i = 0; i < C::BM * S::RCPR / C::NT; ++i) {
+                const int idx = t + C::NT * i;
                 const int row = idx / S::RCPR, j = idx % S::RCPR;
                 if (m0 + row < p.M) {
                     char *dst = (char *)p.res_out + ((size_t)(m0 + row) * p.Cout + c0) * 2 + ((j ^ S::rsw(row)) << 4);
@@ -676,8 +684,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     }
     if (!RES || p.out_q) {
 #pragma unroll
-        for (int i = 0; i < (C::BM * S::QCPR + 255) / 256; ++i) {
-            const int idx = t + 256 * i;
+        for (int i = 0; i < (C::BM * S::QCPR + C::NT - 1) / C::NT; ++i) {
+            const int idx = t + C::NT * i;
             const int row = idx / S::QCPR, j = idx % S::QCPR;
             if (idx < C::BM * S::QCPR && m0 + row < p.M) {
                 const size_t e0 = (size_t)(m0 + row) * p.Cout + c0 + ((j ^ S::qsw(row)) << 4);
@@ -691,7 +699,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 }
 
 template <class C, int EPI, bool DUAL, int BITS, int BITS2>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
+__global__ __launch_bounds__(C::NT, 2) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
     // each XCD a contiguous run of pixel tiles that share the same weight tile in its L2.
@@ -715,10 +723,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const ConvP p) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.ctab + (size_t)(c0 + wave * 64 + lane) * 4),
                                              (__attribute__((address_space(3))) void *)(ctab_lds + wave * 1024), 16, 0, 0);
         if constexpr (DUAL) {
-            if (wave >= 2 && wave - 2 < C::BN / 64)
+            if (wave >= C::NW / 2 && wave - C::NW / 2 < C::BN / 64)
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(p.ctab_id + (size_t)(c0 + (wave - 2) * 64 + lane) * 4),
-                    (__attribute__((address_space(3))) void *)(ctab_lds + C::BN * 16 + (wave - 2) * 1024), 16, 0, 0);
+                    (const __attribute__((address_space(1))) void *)(p.ctab_id + (size_t)(c0 + (wave - C::NW / 2) * 64 + lane) * 4),
+                    (__attribute__((address_space(3))) void *)(ctab_lds + C::BN * 16 + (wave - C::NW / 2) * 1024), 16, 0, 0);
         }
     }
     if constexpr (FAST && EPI == HAWQ_EPI_RESIDUAL && !DUAL) prefetch_residual<C>(p, m0, c0, res_tile);
@@ -765,13 +773,18 @@ using T3 = Cfg<128, 64, 2, 2, 4>;
 using T4 = Cfg<128, 128, 2, 2, 3, 2>;  // K = 128 per barrier
 using T5 = Cfg<64, 64, 2, 2, 4, 2>;
 using T6 = Cfg<128, 64, 2, 2, 3, 2>;
-constexpr int NUM_TILES = 7;
+// 8-wave workgroups: twice the waves issuing LDS-DMA for the same tile (the DMA rate per wave, not the ring
+// depth, bounds the long-K layers when there is at most ~1 workgroup per CU - profiles/r01_ubench_dma_rate.txt)
+using T7 = Cfg<128, 128, 2, 4, 3>;
+using T8 = Cfg<128, 128, 2, 4, 3, 2>;
+using T9 = Cfg<256, 128, 4, 2, 3>;
+constexpr int NUM_TILES = 10;
 
 typedef void (*KernelFn)(const ConvP);
 // single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
 // dual-branch (RESIDUAL + identity conv): {run-time, 88/88, 44/44, 88/44, 44/88}
 struct TileInfo {
-    int BM, BN, lds, ksub, twin;  // twin: tile id with the same BM x BN and KSUB == 1
+    int BM, BN, lds, ksub, twin, nt;  // twin: tile id to fall back to when KSUB == 2 does not divide the chunk count
     KernelFn single[4][3];
     KernelFn dual[5];
 };
@@ -779,7 +792,7 @@ struct TileInfo {
     { conv_kernel<T, E, false, 0, 0>, conv_kernel<T, E, false, 0x88, 0>, conv_kernel<T, E, false, 0x44, 0> }
 #define TILE_ENTRY(T, TWIN)                                                                                          \
     {                                                                                                          \
-        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN,                                                             \
+        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN, T::NT,                                                             \
             {SINGLE_ROW(T, HAWQ_EPI_RAW), SINGLE_ROW(T, HAWQ_EPI_REQUANT), SINGLE_ROW(T, HAWQ_EPI_RESIDUAL),   \
              SINGLE_ROW(T, HAWQ_EPI_DEQUANT)},                                                                 \
         {                                                                                                      \
@@ -790,7 +803,8 @@ struct TileInfo {
         }                                                                                                      \
     }
 const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0, 0), TILE_ENTRY(T1, 1), TILE_ENTRY(T2, 2), TILE_ENTRY(T3, 3),
-                                    TILE_ENTRY(T4, 0), TILE_ENTRY(T5, 2), TILE_ENTRY(T6, 3)};
+                                    TILE_ENTRY(T4, 0), TILE_ENTRY(T5, 2), TILE_ENTRY(T6, 3),
+                                    TILE_ENTRY(T7, 7), TILE_ENTRY(T8, 7), TILE_ENTRY(T9, 9)};
 
 // kernels whose staged epilogue needs more than the default 64 KiB of dynamic LDS
 bool raise_lds_limits() {
@@ -955,7 +969,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     }
     static const bool attrs_ok = raise_lds_limits();  // once per process; never inside a capture
     HAWQ_REQUIRE(attrs_ok, "hawq_conv2d: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(ti.nt), lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

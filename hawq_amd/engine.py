@@ -445,6 +445,7 @@ class IntegerEngine:
         _lib.call("hawq_event_destroy", e0)
         _lib.call("hawq_event_destroy", e1)
         torch.cuda.synchronize(self.dev)
+        self.flags.zero_()  # tuning launches ran on whatever the buffers held; only real forwards may raise the flag
 
     # ------------------------------------------------------------------ execution
     def _launch_all(self):
