@@ -135,6 +135,127 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const int8_t *__restric
     }
 }
 
+
+// ------------------------------------------------------------------ fused stem
+// input quantiser + 7x7/2 conv + bias + 3x3/2 max-pool + QuantAct16 + ReLU + first unit's QuantAct in
+// ONE kernel (q_resnet.py:115-122 + 234/239).  A workgroup owns an 8x8 block of POOLED pixels of two
+// images (one 4x8 sub-block per wave).  The fp32 input patch it needs (39x39 pixels per image) is
+// quantised straight into an int8 NHWC4 LDS patch; each wave then walks the 3x3 pooling window: for
+// window position (dy,dx) one MFMA pixel tile holds conv pixel (2py+dy-1, 2px+dx-1) of the lane's pooled
+// pixel, so the max over the window is a register max over 9 accumulator tiles - taken on the raw
+// accumulators, because the per-channel requantisation is monotone (m > 0) and the bias is constant.
+// The 16-bit conv output at 112x112 (205 MB per 128-image batch) never exists in memory.
+constexpr int SF_PW = 40;                       // patch width in pixels (39 used + 1 zero column)
+constexpr int SF_PATCH = 39 * SF_PW * 4;        // bytes per image patch
+
+__global__ __launch_bounds__(256, 2) void stem_fused_kernel(
+    const float *__restrict__ x, int N, int Cin, int H, int W, float inv_scale, int in_lo, int in_hi,
+    const int8_t *__restrict__ wgt, const int32_t *__restrict__ bias, const int32_t *__restrict__ m,
+    const int32_t *__restrict__ e, int a_lo, int a_hi, int Hc, int Wc, int Hp, int Wp,
+    uint16_t *__restrict__ res_out, void *__restrict__ out_q, int out_bits, int mq, int eq, int q_lo, int q_hi) {
+    __shared__ __attribute__((aligned(16))) char patch[2 * SF_PATCH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int bw = (Wp + 7) >> 3, bh = (Hp + 7) >> 3;
+    int b = blockIdx.x;
+    const int bx = b % bw;
+    b /= bw;
+    const int by = b % bh;
+    const int n0 = (b / bh) * 2;
+    const int py0 = by * 8, px0 = bx * 8;
+
+    // ---- quantise the input patch(es) into LDS: q = clamp(rint(fl(1/S) * x))  (quant_utils.py:73-97)
+    const size_t plane = (size_t)H * W;
+    for (int idx = t; idx < 2 * 39 * SF_PW; idx += 256) {
+        const int img = idx / (39 * SF_PW), rem = idx - img * (39 * SF_PW);
+        const int r = rem / SF_PW, c = rem - r * SF_PW;
+        const int iy = 4 * py0 - 5 + r, ix = 4 * px0 - 5 + c, n = n0 + img;
+        int q[4] = {0, 0, 0, 0};
+        if (n < N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c < 39) {
+            const float *src = x + ((size_t)n * Cin) * plane + (size_t)iy * W + ix;
+            for (int ch = 0; ch < Cin; ++ch) {
+                float v = rintf(__fmul_rn(inv_scale, src[ch * plane]));
+                v = fminf(fmaxf(v, (float)in_lo), (float)in_hi);
+                q[ch] = (int)v;
+            }
+        }
+        *reinterpret_cast<uint32_t *>(patch + idx * 4) = pack4_i8(q[0], q[1], q[2], q[3]);
+    }
+    __syncthreads();
+
+    const int img = wave >> 1;
+    const int pr = (wave & 1) * 4 + (l31 >> 3), pc = l31 & 7;  // pooled pixel of this lane inside the block
+    const int py = py0 + pr, px = px0 + pc, n = n0 + img;
+    const bool pvalid = n < N && py < Hp && px < Wp;
+    const char *pbase = patch + img * SF_PATCH + ((4 * pr) * SF_PW + 4 * pc + 4 * h) * 4;
+    const size_t opix = ((size_t)n * Hp + py) * Wp + px;
+
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {  // two passes of 32 output channels
+        v4i wf[7];
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+            wf[kh] = *reinterpret_cast<const v4i *>(wgt + ((c * 32 + cperm(l31)) * 7 + kh) * 32 + h * 16);
+        int best[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) best[r] = (int)0x80000000;
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {  // not unrolled: keeps the 9 window tiles from living at once
+            const int cy = 2 * py + dy - 1;
+#pragma unroll 1
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cx = 2 * px + dx - 1;
+                const bool cvalid = (unsigned)cy < (unsigned)Hc && (unsigned)cx < (unsigned)Wc;
+                v16i acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) {
+                    const char *s0 = pbase + ((2 * dy + kh) * SF_PW + 2 * dx) * 4;  // 8-byte aligned
+                    const v2i a0 = *reinterpret_cast<const v2i *>(s0), a1 = *reinterpret_cast<const v2i *>(s0 + 8);
+                    v4i af = {a0.x, a0.y, a1.x, a1.y};
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kh], af, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best[r] = max(best[r], cvalid ? acc[r] : (int)0x80000000);
+            }
+        }
+        if (!pvalid) continue;
+        const int ch = c * 32 + h * 16;
+        int r16[16], qa[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4i b4 = *reinterpret_cast<const v4i *>(bias + ch + 4 * g), m4 = *reinterpret_cast<const v4i *>(m + ch + 4 * g),
+                      e4 = *reinterpret_cast<const v4i *>(e + ch + 4 * g);
+            const int bb[4] = {b4.x, b4.y, b4.z, b4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = max(clampi(dyadic_rne(best[4 * g + j] + bb[j], mm[j], ee[j]), a_lo, a_hi), 0);
+                r16[4 * g + j] = v;
+                qa[4 * g + j] = clampi(dyadic_rne(v, mq, eq), q_lo, q_hi);
+            }
+        }
+        if (res_out) {
+            v4i lo, hi;
+            lo.x = r16[0] | (r16[1] << 16), lo.y = r16[2] | (r16[3] << 16), lo.z = r16[4] | (r16[5] << 16), lo.w = r16[6] | (r16[7] << 16);
+            hi.x = r16[8] | (r16[9] << 16), hi.y = r16[10] | (r16[11] << 16), hi.z = r16[12] | (r16[13] << 16), hi.w = r16[14] | (r16[15] << 16);
+            v4i *dst = reinterpret_cast<v4i *>(res_out + opix * 64 + ch);
+            dst[0] = lo;
+            dst[1] = hi;
+        }
+        if (out_q) {
+            if (out_bits == 8) {
+                v4i w = {(int)pack4_i8(qa[0], qa[1], qa[2], qa[3]), (int)pack4_i8(qa[4], qa[5], qa[6], qa[7]),
+                         (int)pack4_i8(qa[8], qa[9], qa[10], qa[11]), (int)pack4_i8(qa[12], qa[13], qa[14], qa[15])};
+                *reinterpret_cast<v4i *>((int8_t *)out_q + opix * 64 + ch) = w;
+            } else {
+                v2i w = {(int)pack8_u4(&qa[0]), (int)pack8_u4(&qa[8])};
+                *reinterpret_cast<v2i *>((uint8_t *)out_q + ((opix * 64 + ch) >> 1)) = w;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ 3x3/2 max-pool (+ QuantAct)
 // thread = 8 channels of one output pixel (16 B of uint16)
 __global__ __launch_bounds__(256) void maxpool_requant_kernel(const uint16_t *__restrict__ in, int N, int H, int W,
@@ -320,6 +441,26 @@ extern "C" int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, 
     HAWQ_REQUIRE(N > 0 && HW > 0 && C > 0, "hawq_avgpool_requant: bad geometry");
     hipLaunchKernelGGL(avgpool_requant_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, in,
                        in_bits, N, HW, C, out, pooled_out, mq, eq, q_lo, q_hi);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t in_lo,
+                               int32_t in_hi, const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e,
+                               int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq,
+                               int32_t eq, int32_t q_lo, int32_t q_hi, void *stream) {
+    HAWQ_REQUIRE(x && wgt && bias && m && e, "hawq_stem_fused: null pointer");
+    HAWQ_REQUIRE(res_out || out_q, "hawq_stem_fused: no output requested");
+    HAWQ_REQUIRE(C >= 1 && C <= 4 && N > 0 && H >= 7 && W >= 7, "hawq_stem_fused: bad geometry");
+    HAWQ_REQUIRE(!out_q || out_bits == 8 || out_bits == 4, "hawq_stem_fused: out_bits 4/8");
+    HAWQ_REQUIRE(a_lo >= -32768 && a_hi <= 65535, "hawq_stem_fused: 16-bit activation range expected");
+    const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;    // conv 7x7 / 2, pad 3
+    const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;  // max-pool 3x3 / 2, pad 1
+    const long long blocks = (long long)((Wp + 7) / 8) * ((Hp + 7) / 8) * ((N + 1) / 2);
+    HAWQ_REQUIRE(blocks < (1ll << 31), "hawq_stem_fused: problem too large");
+    hipLaunchKernelGGL(stem_fused_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, inv_scale,
+                       in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, Hc, Wc, Hp, Wp, res_out, out_q, out_bits, mq, eq, q_lo,
+                       q_hi);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -275,25 +275,33 @@ class IntegerEngine:
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         Hp, Wp = 2 * (Ho - 1) + 7 + 1, 2 * (Wo - 1) + 8
         Hp, Wp = max(Hp, H + 3), max(Wp + (Wp & 1), W + 3 + ((W + 3) & 1))
-        xq = torch.zeros(N * Hp * Wp * 4, dtype=torch.int8, device=dev)
+        unfused = self.keep_acc or bool(os.environ.get("HAWQ_UNFUSED_STEM"))
+        xq = torch.zeros(N * Hp * Wp * 4, dtype=torch.int8, device=dev) if unfused else None
         st = P['stem']
-        stem16 = self._alloc(N * Ho * Wo * 64, torch.uint16)
+        stem16 = self._alloc(N * Ho * Wo * 64, torch.uint16) if unfused else None
         stem_acc = self._alloc(N * Ho * Wo * 64, torch.int32) if self.keep_acc else None
         if stem_acc is not None:
             self.acc_taps['stem'] = (stem_acc, (N, Ho, Wo, 64))
-        ops.append(partial(_lib.call, "hawq_quantize_input", self.x_in.data_ptr(), xq.data_ptr(), N, 3, H, W, Hp, Wp,
-                           3, 3, P['inv_s_in'], -128, 127, sp))
-        c = st['conv']
-        ops.append(partial(_lib.call, "hawq_stem_conv7", xq.data_ptr(), c.w.data_ptr(), c.bias.data_ptr(),
-                           st['m'].data_ptr(), st['e'].data_ptr(), N, Hp, Wp, Ho, Wo, st['rng'][0], st['rng'][1],
-                           stem16.data_ptr(), ptr(stem_acc), sp))
         H1, W1 = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         units = P['units']
         u0 = units[0]
         res = self._alloc(N * H1 * W1 * 64, torch.uint16) if not u0['resize'] else None
         qa = self._alloc(N * H1 * W1 * 64 * u0['a_bits'] // 8, torch.uint8)
-        ops.append(partial(_lib.call, "hawq_maxpool3s2_requant", stem16.data_ptr(), N, Ho, Wo, 64, ptr(res),
-                           qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0], u0['a_rng'][1], sp))
+        c = st['conv']
+        if self.keep_acc or os.environ.get("HAWQ_UNFUSED_STEM"):
+            # three launches with the 112x112 intermediate in memory (exposes the stem accumulators)
+            ops.append(partial(_lib.call, "hawq_quantize_input", self.x_in.data_ptr(), xq.data_ptr(), N, 3, H, W, Hp, Wp,
+                               3, 3, P['inv_s_in'], -128, 127, sp))
+            ops.append(partial(_lib.call, "hawq_stem_conv7", xq.data_ptr(), c.w.data_ptr(), c.bias.data_ptr(),
+                               st['m'].data_ptr(), st['e'].data_ptr(), N, Hp, Wp, Ho, Wo, st['rng'][0], st['rng'][1],
+                               stem16.data_ptr(), ptr(stem_acc), sp))
+            ops.append(partial(_lib.call, "hawq_maxpool3s2_requant", stem16.data_ptr(), N, Ho, Wo, 64, ptr(res),
+                               qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0], u0['a_rng'][1], sp))
+        else:
+            ops.append(partial(_lib.call, "hawq_stem_fused", self.x_in.data_ptr(), N, 3, H, W, P['inv_s_in'], -128, 127,
+                               c.w.data_ptr(), c.bias.data_ptr(), st['m'].data_ptr(), st['e'].data_ptr(), st['rng'][0],
+                               st['rng'][1], ptr(res), qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0],
+                               u0['a_rng'][1], sp))
         keep += [xq, stem16, stem_acc, res, qa]
         h, w = H1, W1
         res_bits_in = 16

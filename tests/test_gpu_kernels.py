@@ -306,6 +306,35 @@ def test_quantize_input_and_stem(lib, orc):
         assert torch.equal(q2, qo)
 
 
+@pytest.mark.parametrize("shape", [(3, 46, 38), (2, 64, 64), (1, 35, 51)])
+def test_fused_stem_matches_unfused_semantics(lib, orc, shape):
+    """hawq_stem_fused == quantize -> conv7x7/2 -> +bias -> max-pool(3,2,1) -> QuantAct16 -> ReLU -> QuantAct
+    (q_resnet.py:115-122), incl. odd sizes, ragged 8x8 blocks and an odd batch."""
+    from hawq_amd.packing import pack_stem_weight
+    from hawq_amd.quant_utils import requant_table
+    n, hh, ww = shape
+    rng = np.random.default_rng(hh * 100 + ww)
+    x = rng.normal(0, 1.3, (n, 3, hh, ww)).astype(f32)
+    scale = f32(0.0213)
+    q_ref = orc.quantize_f32(x, scale, 8)
+    wt = rng.integers(-127, 128, (64, 3, 7, 7)).astype(np.int64)
+    b = rng.integers(-30000, 30000, 64).astype(np.int64)
+    acc = orc.maxpool(orc.conv2d(q_ref, wt, b, 2, 3), 3, 2, 1)
+    m, e = rand_tables(rng, 64, 2e-3, 4e-2)
+    r16 = np.maximum(odyadic(orc, acc, m, e, (-32768, 32767)), 0)
+    mq, eq = requant_table(torch.tensor([0.0041 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+    hp, wp = acc.shape[2:]
+    xd, wd, bd, md, ed = dev(x), dev(pack_stem_weight(wt)), dev(b.astype(np.int32)), dev(m), dev(e)
+    for bits, (lo, hi) in ((8, (-128, 127)), (4, (0, 15))):
+        res = torch.zeros(acc.size, dtype=torch.uint16, device='cuda')
+        qo = torch.zeros(acc.size * bits // 8, dtype=torch.uint8, device='cuda')
+        lib.call("hawq_stem_fused", xd.data_ptr(), n, 3, hh, ww, float(f32(1) / scale), -128, 127, wd.data_ptr(),
+                 bd.data_ptr(), md.data_ptr(), ed.data_ptr(), -32768, 32767, res.data_ptr(), qo.data_ptr(), bits,
+                 int(mq[0]), int(eq[0]), lo, hi, stream())
+        assert np.array_equal(res.cpu().numpy().astype(np.int64).reshape(n, hp, wp, 64).transpose(0, 3, 1, 2), r16)
+        assert np.array_equal(unpack_q(qo, (n, hp, wp, 64), bits), odyadic(orc, r16, mq, eq, (lo, hi)))
+
+
 @pytest.mark.parametrize("res_bits", [16, 32])
 def test_avgpool_requant(lib, orc, res_bits):
     from hawq_amd.quant_utils import requant_table
