@@ -4,6 +4,8 @@
 //   hawq_maxpool3s2_requant  q_resnet.py:93,119 (+ first unit's QuantAct, q_resnet.py:234/239)
 //   hawq_requant_residual    quant_modules.py:288-293 (S_w == 1)
 //   hawq_avgpool_requant     quant_modules.py:596-600, quant_utils.py:334-337, q_resnet.py:129-131
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
     const float *__restrict__ x, int N, int Cin, int H, int W, float inv_scale, int in_lo, int in_hi,
     const int8_t *__restrict__ wgt, const int32_t *__restrict__ bias, const int32_t *__restrict__ m,
     const int32_t *__restrict__ e, int a_lo, int a_hi, int Hc, int Wc, int Hp, int Wp,
-    uint16_t *__restrict__ res_out, void *__restrict__ out_q, int out_bits, int mq, int eq, int q_lo, int q_hi) {
+    uint16_t *__restrict__ res_out, void *__restrict__ out_q, int out_bits, int mq, int eq, int q_lo, int q_hi,
+    int fast, int dbg) {
     __shared__ __attribute__((aligned(16))) char patch[2 * SF_PATCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -166,20 +169,62 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
 
     // ---- quantise the input patch(es) into LDS: q = clamp(rint(fl(1/S) * x))  (quant_utils.py:73-97)
     const size_t plane = (size_t)H * W;
-    for (int idx = t; idx < 2 * 39 * SF_PW; idx += 256) {
-        const int img = idx / (39 * SF_PW), rem = idx - img * (39 * SF_PW);
-        const int r = rem / SF_PW, c = rem - r * SF_PW;
+    auto quant1 = [&](float v) {
+        v = rintf(__fmul_rn(inv_scale, v));
+        return (int)fminf(fmaxf(v, (float)in_lo), (float)in_hi);
+    };
+    // 4 pixels (one 16-B LDS store) per step.  All global loads of the thread's groups are issued before any
+    // is consumed (coordinates are clamped into the image so every load is legal; out-of-image pixels are
+    // zeroed by mask afterwards) - the fill is latency-bound otherwise.
+    constexpr int NG = 2 * 39 * (SF_PW / 4);       // 780 groups of 4 pixels
+    constexpr int GPT = (NG + 255) / 256;          // groups per thread
+    float4 v[GPT][3];
+    int gaddr[GPT];
+    unsigned gmask[GPT];  // bit k: pixel k of the group is inside the image
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) {
+        const int g = t + 256 * k;
+        const int gg = g < NG ? g : NG - 1;
+        const int img = gg / (39 * (SF_PW / 4)), rem = gg - img * (39 * (SF_PW / 4));
+        const int r = rem / (SF_PW / 4), c = (rem - r * (SF_PW / 4)) * 4;
         const int iy = 4 * py0 - 5 + r, ix = 4 * px0 - 5 + c, n = n0 + img;
-        int q[4] = {0, 0, 0, 0};
-        if (n < N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && c < 39) {
-            const float *src = x + ((size_t)n * Cin) * plane + (size_t)iy * W + ix;
-            for (int ch = 0; ch < Cin; ++ch) {
-                float v = rintf(__fmul_rn(inv_scale, src[ch * plane]));
-                v = fminf(fmaxf(v, (float)in_lo), (float)in_hi);
-                q[ch] = (int)v;
+        const bool rowok = g < NG && n < N && (unsigned)iy < (unsigned)H && !(dbg & 16);
+        gaddr[k] = img * SF_PATCH + (r * SF_PW + c) * 4;
+        gmask[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (rowok && (unsigned)(ix + j) < (unsigned)W && c + j < 39) gmask[k] |= 1u << j;
+        const int nn = n < N ? n : N - 1, yy = min(max(iy, 0), H - 1);
+        const float *src = x + ((size_t)nn * Cin) * plane + (size_t)yy * W;
+        const bool interior = ix >= 0 && ix + 3 < W;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            if (ch < Cin) {
+                if (interior) {
+                    v[k][ch] = *reinterpret_cast<const float4 *>(src + ch * plane + ix);
+                } else {
+                    const float *s1 = src + ch * plane;
+                    v[k][ch].x = s1[min(max(ix, 0), W - 1)], v[k][ch].y = s1[min(max(ix + 1, 0), W - 1)];
+                    v[k][ch].z = s1[min(max(ix + 2, 0), W - 1)], v[k][ch].w = s1[min(max(ix + 3, 0), W - 1)];
+                }
+            } else {
+                v[k][ch] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        *reinterpret_cast<uint32_t *>(patch + idx * 4) = pack4_i8(q[0], q[1], q[2], q[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < GPT; ++k) {
+        if (t + 256 * k >= NG) continue;
+        const float px4[4][3] = {{v[k][0].x, v[k][1].x, v[k][2].x}, {v[k][0].y, v[k][1].y, v[k][2].y},
+                                 {v[k][0].z, v[k][1].z, v[k][2].z}, {v[k][0].w, v[k][1].w, v[k][2].w}};
+        int w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (gmask[k] >> j) & 1;
+            w[j] = ok ? (int)pack4_i8(quant1(px4[j][0]), Cin > 1 ? quant1(px4[j][1]) : 0, Cin > 2 ? quant1(px4[j][2]) : 0, 0) : 0;
+        }
+        v4i o = {w[0], w[1], w[2], w[3]};
+        *reinterpret_cast<v4i *>(patch + gaddr[k]) = o;
     }
     __syncthreads();
 
@@ -190,37 +235,47 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
     const char *pbase = patch + img * SF_PATCH + ((4 * pr) * SF_PW + 4 * pc + 4 * h) * 4;
     const size_t opix = ((size_t)n * Hp + py) * Wp + px;
 
-#pragma unroll 1
-    for (int c = 0; c < 2; ++c) {  // two passes of 32 output channels
-        v4i wf[7];
+    // both 32-channel halves share every B fragment read from the LDS patch (the LDS read port, not the
+    // MFMA pipe, is the scarce resource here)
+    v4i wf[2][7];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh)
-            wf[kh] = *reinterpret_cast<const v4i *>(wgt + ((c * 32 + cperm(l31)) * 7 + kh) * 32 + h * 16);
-        int best[16];
+            wf[c][kh] = *reinterpret_cast<const v4i *>(wgt + ((c * 32 + cperm(l31)) * 7 + kh) * 32 + h * 16);
+    int best[2][16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) best[r] = (int)0x80000000;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) best[c][r] = (int)0x80000000;
 #pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy) {  // not unrolled: keeps the 9 window tiles from living at once
-            const int cy = 2 * py + dy - 1;
+    for (int dy = 0; dy < ((dbg & 32) ? 1 : 3); ++dy) {  // not unrolled: keeps the 9 window tiles from living at once
+        const int cy = 2 * py + dy - 1;
 #pragma unroll 1
-            for (int dx = 0; dx < 3; ++dx) {
-                const int cx = 2 * px + dx - 1;
-                const bool cvalid = (unsigned)cy < (unsigned)Hc && (unsigned)cx < (unsigned)Wc;
-                v16i acc;
+        for (int dx = 0; dx < 3; ++dx) {
+            const int cx = 2 * px + dx - 1;
+            const bool cvalid = (unsigned)cy < (unsigned)Hc && (unsigned)cx < (unsigned)Wc;
+            v16i acc0, acc1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0;
+            for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
 #pragma unroll
-                for (int kh = 0; kh < 7; ++kh) {
-                    const char *s0 = pbase + ((2 * dy + kh) * SF_PW + 2 * dx) * 4;  // 8-byte aligned
-                    const v2i a0 = *reinterpret_cast<const v2i *>(s0), a1 = *reinterpret_cast<const v2i *>(s0 + 8);
-                    v4i af = {a0.x, a0.y, a1.x, a1.y};
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kh], af, acc, 0, 0, 0);
-                }
+            for (int kh = 0; kh < 7; ++kh) {
+                const char *s0 = pbase + ((2 * dy + kh) * SF_PW + 2 * dx) * 4;  // 8-byte aligned
+                const v2i a0 = *reinterpret_cast<const v2i *>(s0), a1 = *reinterpret_cast<const v2i *>(s0 + 8);
+                v4i af = {a0.x, a0.y, a1.x, a1.y};
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][kh], af, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[1][kh], af, acc1, 0, 0, 0);
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) best[r] = max(best[r], cvalid ? acc[r] : (int)0x80000000);
+            for (int r = 0; r < 16; ++r) {
+                best[0][r] = max(best[0][r], cvalid ? acc0[r] : (int)0x80000000);
+                best[1][r] = max(best[1][r], cvalid ? acc1[r] : (int)0x80000000);
             }
         }
-        if (!pvalid) continue;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (!pvalid || (dbg & 64)) continue;
         const int ch = c * 32 + h * 16;
         int r16[16], qa[16];
 #pragma unroll
@@ -228,11 +283,21 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
             const v4i b4 = *reinterpret_cast<const v4i *>(bias + ch + 4 * g), m4 = *reinterpret_cast<const v4i *>(m + ch + 4 * g),
                       e4 = *reinterpret_cast<const v4i *>(e + ch + 4 * g);
             const int bb[4] = {b4.x, b4.y, b4.z, b4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
+            if (fast) {  // host-proved tie-free tables (hawq_amd.quant_utils.tables_are_fast): 3-instruction requant
+                const DyNt dq = dynt_prepare(mq, eq);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int v = max(clampi(dyadic_rne(best[4 * g + j] + bb[j], mm[j], ee[j]), a_lo, a_hi), 0);
-                r16[4 * g + j] = v;
-                qa[4 * g + j] = clampi(dyadic_rne(v, mq, eq), q_lo, q_hi);
+                for (int j = 0; j < 4; ++j) {
+                    const int v = max(clampi(dyadic_nt(best[c][4 * g + j] + bb[j], dynt_prepare(mm[j], ee[j])), a_lo, a_hi), 0);
+                    r16[4 * g + j] = v;
+                    qa[4 * g + j] = clampi(dyadic_nt(v, dq), q_lo, q_hi);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int v = max(clampi(dyadic_rne(best[c][4 * g + j] + bb[j], mm[j], ee[j]), a_lo, a_hi), 0);
+                    r16[4 * g + j] = v;
+                    qa[4 * g + j] = clampi(dyadic_rne(v, mq, eq), q_lo, q_hi);
+                }
             }
         }
         if (res_out) {
@@ -448,10 +513,11 @@ extern "C" int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, 
 extern "C" int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t in_lo,
                                int32_t in_hi, const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e,
                                int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq,
-                               int32_t eq, int32_t q_lo, int32_t q_hi, void *stream) {
+                               int32_t eq, int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream) {
     HAWQ_REQUIRE(x && wgt && bias && m && e, "hawq_stem_fused: null pointer");
+    HAWQ_REQUIRE(!fast_tables || ((eq & 0xff) >= 33 && (eq & 0xff) <= 62), "hawq_stem_fused: fast_tables needs eq in [33,62]");
     HAWQ_REQUIRE(res_out || out_q, "hawq_stem_fused: no output requested");
-    HAWQ_REQUIRE(C >= 1 && C <= 4 && N > 0 && H >= 7 && W >= 7, "hawq_stem_fused: bad geometry");
+    HAWQ_REQUIRE(C >= 1 && C <= 3 && N > 0 && H >= 7 && W >= 7, "hawq_stem_fused: bad geometry (C <= 3)");
     HAWQ_REQUIRE(!out_q || out_bits == 8 || out_bits == 4, "hawq_stem_fused: out_bits 4/8");
     HAWQ_REQUIRE(a_lo >= -32768 && a_hi <= 65535, "hawq_stem_fused: 16-bit activation range expected");
     const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;    // conv 7x7 / 2, pad 3
@@ -460,7 +526,7 @@ extern "C" int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, 
     HAWQ_REQUIRE(blocks < (1ll << 31), "hawq_stem_fused: problem too large");
     hipLaunchKernelGGL(stem_fused_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, inv_scale,
                        in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, Hc, Wc, Hp, Wp, res_out, out_q, out_bits, mq, eq, q_lo,
-                       q_hi);
+                       q_hi, fast_tables, getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

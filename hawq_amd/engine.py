@@ -153,7 +153,8 @@ class IntegerEngine:
         a0 = m.quant_act_int32
         s0 = self._scale(a0)
         mm, ee = requant_table(s_in, sc.s_w, s0, vbits=sc.vbits)
-        P['stem'] = dict(conv=sc, m=_i32(mm, dev), e=_i32(ee, dev), rng=_act_range(a0.activation_bit, a0.quant_mode))
+        P['stem'] = dict(conv=sc, m=_i32(mm, dev), e=_i32(ee, dev), rng=_act_range(a0.activation_bit, a0.quant_mode),
+                         fast=tables_are_fast(mm, ee, sc.vbits))
         s_prev = s0
         units = []
         for name, u in m.units():
@@ -164,6 +165,8 @@ class IntegerEngine:
             d['a_rng'] = _act_range(qa.activation_bit, qa.quant_mode)
             mq, eq = requant_table(s_prev, one, s_a, vbits=RES_VBITS)
             d['mq'], d['eq'] = int(mq[0]), int(eq[0])
+            if not units:  # the stem kernel applies the first unit's QuantAct
+                P['stem']['fast'] = P['stem']['fast'] and tables_are_fast(mq, eq, U16_VBITS)
             if d['resize']:
                 d['ident'] = _Conv(u.quant_identity_convbn, s_a, d['a_bits'], dev, self.from_buffers)
             s_x, bits_x = s_a, d['a_bits']
@@ -301,7 +304,7 @@ class IntegerEngine:
             ops.append(partial(_lib.call, "hawq_stem_fused", self.x_in.data_ptr(), N, 3, H, W, P['inv_s_in'], -128, 127,
                                c.w.data_ptr(), c.bias.data_ptr(), st['m'].data_ptr(), st['e'].data_ptr(), st['rng'][0],
                                st['rng'][1], ptr(res), qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0],
-                               u0['a_rng'][1], sp))
+                               u0['a_rng'][1], int(st['fast'] and self.fast), sp))
         keep += [xq, stem16, stem_acc, res, qa]
         h, w = H1, W1
         res_bits_in = 16

@@ -130,11 +130,12 @@ int hawq_stem_conv7(const int8_t *in, const int8_t *wgt, const int32_t *bias, co
 /* Fused stem: QuantAct input case + 7x7/2 conv + bias + MaxPool2d(3,2,1) + QuantAct(16b, clamp) + ReLU
  * + first unit's QuantAct in one launch (q_resnet.py:115-122, 234/239): fp32 NCHW images ->
  * res_out [N][Hp][Wp][64] uint16 and/or out_q int8/hawq4.  The max-pool is taken on the raw accumulators
- * (the per-channel requantisation is monotone), so the 112x112 intermediate never reaches memory. */
+ * (the per-channel requantisation is monotone), so the 112x112 intermediate never reaches memory.
+ * fast_tables: the caller asserts the fast contract for (m, e) and (mq, eq) (see hawq_conv_args). */
 int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t in_lo,
                     int32_t in_hi, const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e,
                     int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq,
-                    int32_t eq, int32_t q_lo, int32_t q_hi, void *stream);
+                    int32_t eq, int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream);
 
 /* nn.MaxPool2d(3,2,1) (q_resnet.py:93,119) on the requantised stem output + the first
  * unit's QuantAct: in [N][H][W][C] uint16 -> res_out [N][Ho][Wo][C] uint16 and

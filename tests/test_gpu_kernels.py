@@ -325,12 +325,14 @@ def test_fused_stem_matches_unfused_semantics(lib, orc, shape):
     mq, eq = requant_table(torch.tensor([0.0041 * 0.7]), torch.ones(1), torch.tensor([0.7]))
     hp, wp = acc.shape[2:]
     xd, wd, bd, md, ed = dev(x), dev(pack_stem_weight(wt)), dev(b.astype(np.int32)), dev(m), dev(e)
-    for bits, (lo, hi) in ((8, (-128, 127)), (4, (0, 15))):
+    from hawq_amd.quant_utils import tables_are_fast
+    can_fast = tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1) and tables_are_fast(mq, eq, 17)
+    for bits, (lo, hi), fast in ((8, (-128, 127), 0), (4, (0, 15), 0), (8, (-128, 127), int(can_fast))):
         res = torch.zeros(acc.size, dtype=torch.uint16, device='cuda')
         qo = torch.zeros(acc.size * bits // 8, dtype=torch.uint8, device='cuda')
         lib.call("hawq_stem_fused", xd.data_ptr(), n, 3, hh, ww, float(f32(1) / scale), -128, 127, wd.data_ptr(),
                  bd.data_ptr(), md.data_ptr(), ed.data_ptr(), -32768, 32767, res.data_ptr(), qo.data_ptr(), bits,
-                 int(mq[0]), int(eq[0]), lo, hi, stream())
+                 int(mq[0]), int(eq[0]), lo, hi, fast, stream())
         assert np.array_equal(res.cpu().numpy().astype(np.int64).reshape(n, hp, wp, 64).transpose(0, 3, 1, 2), r16)
         assert np.array_equal(unpack_q(qo, (n, hp, wp, 64), bits), odyadic(orc, r16, mq, eq, (lo, hi)))
 
