@@ -239,9 +239,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class C, bool DUAL>
-__device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1],
-                                                const ConvP &p, int m0, int c0, char *smem) {
+// NIB: both operands are hawq4 nibble-packed.  A ring-stage row still holds 64 BYTES (= 128 channels), the
+// packed bytes travel through LDS untouched and every fragment (8 B = 16 channels per lane) is unpacked to
+// int8 in registers right before its MFMA (activations zero-extended, weights as value*16 with the
+// accumulators shifted back by 4 at the end - exact).  Needs Cin % 128 == 0 (launcher-checked).
+template <class C, bool DUAL, bool NIB>
+__device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1],
+                                              const ConvP &p, int m0, int c0, char *smem) {
+    constexpr int CSH = NIB ? 7 : 6;  // log2(channels per 64-byte chunk)
     constexpr int NS = C::NS, L = C::AL + C::WL, STAGE = C::STAGE_BYTES;
     static_assert((NS - 2) * L * C::KSUB <= 60, "vmcnt range");
     const int t = threadIdx.x;
@@ -273,9 +278,10 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
 #pragma unroll
     for (int j = 0; j < C::WL; ++j) wsw[j] = (lslot ^ (((lrow + C::RPP * j) >> 2) & 3)) << 4;
 
-    const int taps = p.KH * p.KW, cch1 = p.Cin >> 6;
-    const int nk1 = taps * cch1, nk2 = DUAL ? (p.Cin2 >> 6) : 0, nk = nk1 + nk2;
-    const size_t wrow1 = (size_t)taps * p.Cin, wrow2 = DUAL ? (size_t)p.Cin2 : 0;
+    const int taps = p.KH * p.KW, cch1 = p.Cin >> CSH;
+    const int nk1 = taps * cch1, nk2 = DUAL ? (p.Cin2 >> CSH) : 0, nk = nk1 + nk2;
+    const int rowb1 = NIB ? p.Cin >> 1 : p.Cin, rowb2 = DUAL ? (NIB ? p.Cin2 >> 1 : p.Cin2) : 0;  // bytes per pixel / tap row
+    const size_t wrow1 = (size_t)taps * rowb1, wrow2 = (size_t)rowb2;
 
     constexpr int KSUB = C::KSUB, SUBB = (C::BM + C::BN) * 64;  // bytes of one 64-channel sub-chunk (A rows, then W rows)
     int kh = 0, kw = 0, cc = 0, jissue = 0, istage = 0;  // coordinates of the next sub-chunk to ISSUE
@@ -288,14 +294,14 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
             for (int i = 0; i < C::AL; ++i) {
                 const int iy = iy0[i] + kh, ix = ix0[i] + kw;
                 const bool v = mval[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const char *src = v ? (const char *)p.in + (size_t)(pix_base[i] + tap_off) * p.Cin + (cc << 6) + asw[i] : zero;
+                const char *src = v ? (const char *)p.in + (size_t)(pix_base[i] + tap_off) * rowb1 + (cc << 6) + asw[i] : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sa + i * (C::RPP * 64)), 16, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < C::WL; ++j) {
                 const char *src = (const char *)p.wgt + (size_t)(c0 + lrow + C::RPP * j) * wrow1 +
-                                  (size_t)((kh * p.KW + kw) * p.Cin + (cc << 6)) + wsw[j];
+                                  (size_t)((kh * p.KW + kw) * rowb1 + (cc << 6)) + wsw[j];
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sw + j * (C::RPP * 64)), 16, 0, 0);
             }
@@ -310,7 +316,7 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
             const int c2 = jissue - nk1;
 #pragma unroll
             for (int i = 0; i < C::AL; ++i) {
-                const char *src = mval[i] ? (const char *)p.in2 + (size_t)pix2[DUAL ? i : 0] * p.Cin2 + (c2 << 6) + asw[i] : zero;
+                const char *src = mval[i] ? (const char *)p.in2 + (size_t)pix2[DUAL ? i : 0] * rowb2 + (c2 << 6) + asw[i] : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sa + i * (C::RPP * 64)), 16, 0, 0);
             }
@@ -339,8 +345,23 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     auto compute = [&](auto &a, int stage) {
         // fragments of K-step s+1 are fetched from LDS while the MFMAs of K-step s run
         v4i wf[2][C::CT], af[2][C::PT];
+        constexpr int SPS = NIB ? 4 : 2;  // MFMA K-steps per 64-byte sub-chunk
         auto fetch = [&](int s, int buf) {
-            const char *ldsA = smem + stage * STAGE + (s >> 1) * SUBB, *ldsW = ldsA + C::BM * 64;
+            const char *ldsA = smem + stage * STAGE + (s / SPS) * SUBB, *ldsW = ldsA + C::BM * 64;
+            if constexpr (NIB) {
+                const int slot = s % SPS;  // 16 packed bytes = 32 channels; lane-half h takes 8 of them
+#pragma unroll
+                for (int c = 0; c < C::CT; ++c) {
+                    const v2i t2 = *reinterpret_cast<const v2i *>(ldsW + lds_off(wrow[c], slot) + h * 8);
+                    wf[buf][c] = unpack16<true>((unsigned)t2.x, (unsigned)t2.y);
+                }
+#pragma unroll
+                for (int q = 0; q < C::PT; ++q) {
+                    const v2i t2 = *reinterpret_cast<const v2i *>(ldsA + lds_off(arow[q], slot) + h * 8);
+                    af[buf][q] = unpack16<false>((unsigned)t2.x, (unsigned)t2.y);
+                }
+                return;
+            }
             const int slot = 2 * (s & 1) + h;
 #pragma unroll
             for (int c = 0; c < C::CT; ++c) wf[buf][c] = *reinterpret_cast<const v4i *>(ldsW + lds_off(wrow[c], slot));
@@ -349,8 +370,8 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
         };
         fetch(0, 0);
 #pragma unroll
-        for (int s = 0; s < 2 * KSUB; ++s) {
-            if (s + 1 < 2 * KSUB) fetch(s + 1, (s + 1) & 1);
+        for (int s = 0; s < SPS * KSUB; ++s) {
+            if (s + 1 < SPS * KSUB) fetch(s + 1, (s + 1) & 1);
 #pragma unroll
             for (int c = 0; c < C::CT; ++c)
 #pragma unroll
@@ -388,6 +409,17 @@ __device__ __forceinline__ void gemm_pipeline88(v16i (&acc)[C::CT][C::PT], v16i 
     for (int k = 0; k < ns1; ++k) step(acc, k);
     if constexpr (DUAL)
         for (int k = ns1; k < nst; ++k) step(acc2, k);
+    if constexpr (NIB) {  // weights were unpacked as value*16
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[c][q][r] >>= 4;
+                    if constexpr (DUAL) acc2[DUAL ? c : 0][DUAL ? q : 0][r] >>= 4;
+                }
+    }
     __syncthreads();  // all MFMA fragment reads done: the ring may be reused by the epilogue
 }
 
@@ -747,9 +779,13 @@ __global__ __launch_bounds__(C::NT, 2) void conv_kernel(const ConvP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[c][q][r] = 0;
     }
-    constexpr bool ASYNC = BITS == 0x88 && (!DUAL || BITS2 == 0x88);
-    if constexpr (ASYNC) {
-        gemm_pipeline88<C, DUAL>(acc, acc2, p, m0, c0, smem);
+    constexpr bool ASYNC8 = BITS == 0x88 && (!DUAL || BITS2 == 0x88);
+    constexpr bool ASYNC4 = BITS == 0x44 && (!DUAL || BITS2 == 0x44);
+    if constexpr (ASYNC8) {
+        gemm_pipeline<C, DUAL, false>(acc, acc2, p, m0, c0, smem);
+    } else if (ASYNC4 && (p.Cin & 127) == 0 && (!DUAL || (p.Cin2 & 127) == 0) &&
+               ((p.KH * p.KW * (p.Cin >> 7)) % C::KSUB) == 0 && (!DUAL || ((p.Cin2 >> 7) % C::KSUB) == 0)) {
+        if constexpr (ASYNC4) gemm_pipeline<C, DUAL, true>(acc, acc2, p, m0, c0, smem);
     } else {
         run_segment<C, BITS>(acc, p.in, p.wgt, p.in_bits, p.w_bits, p.H, p.W, p.Cin, p.KH, p.KW, p.stride, p.pad,
                              p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
@@ -943,7 +979,9 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (kTiles[tile].ksub > 1) {  // K = 128 per barrier: int8 x int8 async pipeline with even chunk counts only
         const int nk1 = a->KH * a->KW * (a->Cin >> 6), nk2 = dual ? (a->Cin2 >> 6) : 0;
         const bool all88 = a->in_bits == 8 && a->w_bits == 8 && (!dual || (a->in2_bits == 8 && a->w2_bits == 8));
-        if (!all88 || (nk1 % kTiles[tile].ksub) || (nk2 % kTiles[tile].ksub)) tile = kTiles[tile].twin;
+        // (4/4 layers check the divisibility of their 128-channel chunk count inside the kernel and otherwise
+        //  run the register-staged loop, which works for any tile)
+        if (all88 && ((nk1 % kTiles[tile].ksub) || (nk2 % kTiles[tile].ksub))) tile = kTiles[tile].twin;
     }
     const TileInfo &ti = kTiles[tile];
     const int grid = ((p.M + ti.BM - 1) / ti.BM) * (p.Cout / ti.BN);
