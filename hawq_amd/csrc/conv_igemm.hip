@@ -800,6 +800,162 @@ __global__ __launch_bounds__(C::NT, 2) void conv_kernel(const ConvP p) {
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
 
+// =============================================================== 3x3 / stride 1 / pad 1 "band" kernel
+// The generic pipeline re-fetches the activation tile once per filter tap (9x).  Here a workgroup that owns
+// 256 consecutive output pixels keeps, per 64-channel slice, the whole input BAND those pixels touch
+// (their image rows plus one halo row above and below, each row with a zero column left and right) in LDS
+// and reads the nine taps' B fragments from it at shifted addresses: activation traffic into LDS drops ~7x,
+// only the 9 small weight tiles of the slice are streamed.  Band rows are GLOBAL rows G = n*Ho + y, so the
+// fill needs no image logic; a tap whose row falls outside the pixel's own image is zeroed at fragment time.
+//   band ring : 2 stages x 512 band pixels x 64 B     (LDS-DMA, source-side XOR swizzle as everywhere)
+//   W ring    : 3 stages x BN x 64 B, one stage per (slice, tap) step, issued two steps ahead
+template <int BN_, int WM_, int WN_>
+struct BandCfg {
+    static constexpr int BM = 256, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int NW = WM * WN, NT = NW * 64;
+    static constexpr int PT = BM / WM / 32, CT = BN / WN / 32;
+    static constexpr int BAND_PX = 512;                       // band pixels per stage (upper bound, launcher-checked)
+    static constexpr int BAND_BYTES = BAND_PX * 64;
+    static constexpr int BP = BAND_PX / (16 * NW);            // LDS-DMA instructions per wave per band stage
+    static constexpr int WSTAGE = BN * 64;
+    static constexpr int WLOADERS = BN * 4 / 64;              // waves that issue the (single) W instruction of a step
+    static constexpr int LDS_BYTES = 2 * BAND_BYTES + 3 * WSTAGE;
+    static_assert(WLOADERS <= NW && BP >= 1, "tile shape");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NT, 2) void conv3x3_band_kernel(const ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_c = p.Cout / C::BN;
+    const int nwg = ((p.M + C::BM - 1) / C::BM) * tiles_c;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tc = wg % tiles_c, tm = wg / tiles_c;
+    const int m0 = tm * C::BM, c0 = tc * C::BN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
+    const int l31 = lane & 31, h = lane >> 5, lslot = lane & 3;
+    char *band = smem, *wring = smem + 2 * C::BAND_BYTES, *ctab_lds = smem + C::LDS_BYTES;
+    const char *zero = reinterpret_cast<const char *>(g_zero16);
+
+    if (wave < C::BN / 64)  // requant constants of this channel tile -> LDS, off the critical path
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.ctab + (size_t)(c0 + wave * 64 + lane) * 4),
+                                         (__attribute__((address_space(3))) void *)(ctab_lds + wave * 1024), 16, 0, 0);
+
+    const int Wo = p.Wo, Wb = Wo + 2;
+    const int G0 = m0 / Wo - 1;                 // global row held by band row 0
+    const int rows_total = p.N * p.Ho;
+    // ---- band fill bookkeeping: this lane's band pixel in each of the BP passes
+    const char *bsrc[C::BP];
+#pragma unroll
+    for (int i = 0; i < C::BP; ++i) {
+        const int bpx = (i * C::NW + wave) * 16 + (lane >> 2);
+        const int br = bpx / Wb, bc = bpx - br * Wb;
+        const int G = G0 + br, x = bc - 1;
+        const bool v = (unsigned)G < (unsigned)rows_total && (unsigned)x < (unsigned)Wo;
+        bsrc[i] = v ? (const char *)p.in + ((size_t)G * Wo + x) * p.Cin + ((lslot ^ ((bpx >> 2) & 3)) << 4) : nullptr;
+    }
+    const int cchunks = p.Cin >> 6;
+    const int nsteps = 9 * cchunks;
+    const size_t wrow = (size_t)9 * p.Cin;
+    const char *wsrc = (const char *)p.wgt + (size_t)(c0 + wave * 16 + (lane >> 2)) * wrow +
+                       ((lslot ^ (((wave * 16 + (lane >> 2)) >> 2) & 3)) << 4);
+    const bool wloader = wave < C::WLOADERS;
+
+    auto issue_band = [&](int cc) {
+        char *dst = band + (cc & 1) * C::BAND_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < C::BP; ++i) {
+            const char *src = bsrc[i] ? bsrc[i] + (cc << 6) : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + i * (C::NW * 1024)), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int s) {  // step s = cc * 9 + tap
+        if (!wloader) return;
+        const int cc = s / 9, tap = s - cc * 9;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)tap * p.Cin + (cc << 6)),
+                                         (__attribute__((address_space(3))) void *)(wring + (s % 3) * C::WSTAGE + wave * 1024), 16, 0, 0);
+    };
+
+    // ---- per-lane output pixel geometry
+    int bp0[C::PT], yy[C::PT];
+#pragma unroll
+    for (int q = 0; q < C::PT; ++q) {
+        const int m = m0 + wave_m * (C::PT * 32) + q * 32 + l31;
+        const int G = m / Wo, x = m - G * Wo;
+        bp0[q] = (G - G0 - 1) * Wb + x;   // band pixel of tap (kh=0, kw=0)
+        yy[q] = G % p.Ho;
+    }
+    int wrw[C::CT];
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) wrw[c] = wave_c * (C::CT * 32) + c * 32 + cperm(l31);
+
+    v16i acc[C::CT][C::PT];
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+        for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
+
+    issue_band(0);
+    issue_w(0);
+    if (nsteps > 1) issue_w(1);
+    const int myw = wloader ? 1 : 0;
+    int cc = 0, tap = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // loads issued after W(s): W(s+1) if it exists, plus the band prefetch issued one or two steps ago
+        int allowed = (s + 1 < nsteps) ? myw : 0;
+        if ((tap == 1 || tap == 2) && cc + 1 < cchunks) allowed += C::BP;
+        switch (allowed) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<1>(); break;
+            case C::BP: wait_vmcnt<C::BP>(); break;
+            default: wait_vmcnt<C::BP + 1>(); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < nsteps) issue_w(s + 2);
+        if (tap == 0 && cc + 1 < cchunks) issue_band(cc + 1);
+
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const char *bst = band + (cc & 1) * C::BAND_BYTES, *wst = wring + (s % 3) * C::WSTAGE;
+        const int toff = kh * Wb + kw;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = 2 * ks + h;
+            v4i wf[C::CT], af[C::PT];
+#pragma unroll
+            for (int c = 0; c < C::CT; ++c) wf[c] = *reinterpret_cast<const v4i *>(wst + lds_off(wrw[c], slot));
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q) {
+                const int bp = bp0[q] + toff;
+                v4i a = *reinterpret_cast<const v4i *>(bst + bp * 64 + ((slot ^ ((bp >> 2) & 3)) << 4));
+                if ((unsigned)(yy[q] + kh - 1) >= (unsigned)p.Ho) a = v4i{0, 0, 0, 0};  // row of another image / padding
+                af[q] = a;
+            }
+#pragma unroll
+            for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+                for (int q = 0; q < C::PT; ++q)
+                    acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[c], af[q], acc[c][q], 0, 0, 0);
+        }
+        if (++tap == 9) {
+            tap = 0;
+            ++cc;
+        }
+    }
+    __syncthreads();
+    v16i dummy[1][1];
+    epilogue_fast<C, HAWQ_EPI_REQUANT, false>(p, acc, dummy, m0, c0, smem, smem, ctab_lds);
+}
+
+using B0 = BandCfg<64, 4, 1>;    // Cout == 64 layers (stage 1): 4 waves x (64 px x 64 ch)
+using B1 = BandCfg<128, 4, 2>;   // 8 waves x (64 px x 64 ch)
+
 using T0 = Cfg<128, 128, 2, 2, 3>;
 using T1 = Cfg<256, 64, 4, 1, 3>;
 using T2 = Cfg<64, 64, 2, 2, 4>;
@@ -872,7 +1028,7 @@ int pick_tile(int M, int Cout, bool dual) {
 
 }  // namespace
 
-extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES; }
+extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + 2; }  // + the two 3x3 band kernels
 
 extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     HAWQ_REQUIRE(a != nullptr, "hawq_conv2d: null args");
@@ -974,6 +1130,25 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             HAWQ_REQUIRE(false, "hawq_conv2d: unknown epilogue %d", a->epilogue);
     }
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
+    if (tile >= NUM_TILES && tile < NUM_TILES + 2) {
+        // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 REQUANT layers only
+        const int bn = tile == NUM_TILES ? 64 : 128;
+        const int wo = p.Wo, band_rows = (256 + wo - 1) / wo + 1 + 2;
+        const bool ok = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && !dual && fast &&
+                        a->epilogue == HAWQ_EPI_REQUANT && a->in_bits == 8 && a->w_bits == 8 && p.Cout % bn == 0 &&
+                        band_rows * (wo + 2) <= 512 && a->out_q;
+        HAWQ_REQUIRE(ok, "hawq_conv2d: tile %d (3x3 band kernel) does not apply to this layer", a->tile);
+        static const bool band_attrs = hipFuncSetAttribute((const void *)conv3x3_band_kernel<B0>, hipFuncAttributeMaxDynamicSharedMemorySize, B0::LDS_BYTES + 4096) == hipSuccess &&
+                                       hipFuncSetAttribute((const void *)conv3x3_band_kernel<B1>, hipFuncAttributeMaxDynamicSharedMemorySize, B1::LDS_BYTES + 4096) == hipSuccess;
+        HAWQ_REQUIRE(band_attrs, "hawq_conv2d: hipFuncSetAttribute failed for the band kernels");
+        const int grid_b = ((p.M + 255) / 256) * (p.Cout / bn);
+        if (bn == 64)
+            hipLaunchKernelGGL(conv3x3_band_kernel<B0>, dim3(grid_b), dim3(B0::NT), B0::LDS_BYTES + B0::BN * 16, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(conv3x3_band_kernel<B1>, dim3(grid_b), dim3(B1::NT), B1::LDS_BYTES + B1::BN * 16, (hipStream_t)stream, p);
+        HAWQ_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     HAWQ_REQUIRE(tile >= 0 && tile < NUM_TILES, "hawq_conv2d: bad tile id %d", a->tile);
     if (p.Cout % kTiles[tile].BN != 0) tile = 2;
     if (kTiles[tile].ksub > 1) {  // K = 128 per barrier: int8 x int8 async pipeline with even chunk counts only

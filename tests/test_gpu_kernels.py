@@ -109,7 +109,7 @@ def test_conv_raw_accumulators(lib, orc, shape, bits):
     rng = np.random.default_rng(hash((shape, bits)) % 2 ** 32)
     x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
     ref = orc.conv2d(x, wt, b, stride, pad)
-    for tile in range(0, lib.load().hawq_conv2d_num_tiles() + 1):
+    for tile in range(0, lib.load().hawq_conv2d_num_tiles() + 1 - 2):  # the last two ids are the 3x3 band kernels
         a, keep = conv_args(lib, x, wt, b, stride, pad, *bits, tile=tile)
         out = torch.full((ref.size,), -7, dtype=torch.int32, device='cuda')
         a.epilogue, a.out_acc = lib.EPI_RAW, out.data_ptr()
@@ -167,6 +167,40 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
         a.relu = 0
         lib.call("hawq_conv2d", C.byref(a), stream())
         assert np.array_equal(unpack_q(out, (n, h, w, cout), 8), odyadic(orc, acc, m, e, (lo, hi)))
+
+
+@pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (9, 7, 7, 128, 128),
+                                   (1, 14, 20, 64, 192), (2, 9, 30, 192, 64)])
+def test_conv3x3_band_kernels(lib, orc, shape):
+    """The LDS-band 3x3 kernels (tile ids N-1, N) vs the oracle: all ResNet50 spatial sizes, several images per
+    workgroup, ragged last tile, rectangular maps; both ReLU settings; int8 and hawq4 outputs."""
+    from hawq_amd.packing import pack_ctab
+    from hawq_amd.quant_utils import tables_are_fast
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(h * 1000 + w + cin)
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 3, 8, 8)
+    acc = orc.conv2d(x, wt, b, 1, 1)
+    m, e = rand_tables(rng, cout, 2e-5, 3e-4)
+    assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
+    ntiles = lib.load().hawq_conv2d_num_tiles()
+    ran = 0
+    for tile in (ntiles - 1, ntiles):
+        if cout % (64 if tile == ntiles - 1 else 128):
+            continue
+        for relu, out_bits, (lo, hi) in ((1, 8, (-128, 127)), (0, 8, (-128, 127)), (1, 4, (0, 15))):
+            a, keep = conv_args(lib, x, wt, b, 1, 1, 8, 8, tile=tile)
+            keep.update(ctab=dev(pack_ctab(b, m, e)), m=dev(m), e=dev(e))
+            out = torch.zeros(acc.size * out_bits // 8, dtype=torch.uint8, device='cuda')
+            a.epilogue, a.relu, a.m, a.e, a.ctab, a.fast_tables = lib.EPI_REQUANT, relu, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), 1
+            a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), out_bits, lo, hi
+            lib.call("hawq_conv2d", C.byref(a), stream())
+            ref = odyadic(orc, np.maximum(acc, 0) if relu else acc, m, e, (lo, hi))
+            assert np.array_equal(unpack_q(out, (n, h, w, cout), out_bits), ref), (tile, relu, out_bits)
+            ran += 1
+    assert ran >= 3
+    # a layer the band kernels cannot take is refused, not mis-computed
+    a, keep = conv_args(lib, x, wt, b, 2, 1, 8, 8, tile=ntiles)
+    assert lib.load().hawq_conv2d(C.byref(a), None) != 0
 
 
 @pytest.mark.parametrize("fast", [0, 1])
