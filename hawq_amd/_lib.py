@@ -42,6 +42,7 @@ SIGNATURES = {
     "hawq_device_ok": [],
     "hawq_conv2d": [C.POINTER(ConvArgs), vp],
     "hawq_conv2d_num_tiles": [],
+    "hawq_conv2d_num_band_tiles": [],
     "hawq_quantize_input": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "hawq_stem_conv7": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_stem_fused": [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32,

@@ -15,6 +15,7 @@
 //
 // Reference arithmetic replaced: quant_modules.py:489-494 (conv), q_resnet.py:242-258 (ReLU,
 // residual add), quant_utils.py:390-456 (fixedpoint_fn case 0 / case 1).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -45,6 +46,7 @@ struct ConvP {
     int32_t *flags;
     const int32_t *ctab, *ctab_id;
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
+    long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
 
 template <int BM_, int BN_, int WM_, int WN_, int NS_, int KSUB_ = 1>
@@ -237,6 +239,28 @@ __device__ __attribute__((aligned(16))) const int g_zero16[4] = {0, 0, 0, 0};
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Hand-issued LDS fragment reads.  hipcc treats every LDS-DMA instruction as a pending FLAT access and from then
+// on only ever emits `s_waitcnt lgkmcnt(0)` (measured on a toy kernel: lgkmcnt(2) without, lgkmcnt(0) with one
+// global_load_lds in the loop), so compiler-visible ds_reads cannot be software-pipelined in these kernels.
+// Reads issued through lds_read16 are invisible to its bookkeeping: the caller waits with wait_lgkm<N>() (N =
+// reads allowed to stay in flight; LDS returns in order, and a scalar load that happens to be in flight can
+// only make the wait stricter, never too lax, as long as N counts LDS reads issued AFTER the ones needed) and
+// then passes every fragment through pin() before its first use.
+template <int OFF>
+__device__ __forceinline__ v4i lds_read16(unsigned addr) {
+    v4i r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin(v4i &f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ unsigned lds_addr(const char *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
 }
 
 // NIB: both operands are hawq4 nibble-packed.  A ring-stage row still holds 64 BYTES (= 128 channels), the
@@ -585,11 +609,13 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
 template <class C, int EPI, bool DUAL>
 __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
                                               v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
-                                              char *q_tile, char *res_tile, const char *ctab_lds) {
+                                              char *q_tile, char *res_tile, const char *ctab_lds,
+                                              const bool active = true) {
+    // active == false: a wave that owns no accumulators (band-kernel producer); it only helps with the stores
     using S = Stage<C>;
     constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
+    const int wave_m = wave % C::WM, wave_c = (wave / C::WM) % C::WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int lrow0 = wave_m * (C::PT * 32) + l31;  // tile-local pixel row of pixel tile 0
     const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
@@ -597,6 +623,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     unsigned rowmask[C::PT];
 #pragma unroll
     for (int q = 0; q < C::PT; ++q) rowmask[q] = (m0 + lrow0 + q * 32 < p.M) ? 0xffffffffu : 0u;
+    if (active)
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
         const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;  // tile-local first channel of this lane
@@ -801,31 +828,48 @@ __global__ __launch_bounds__(C::NT, 2) void conv_kernel(const ConvP p) {
 }
 
 // =============================================================== 3x3 / stride 1 / pad 1 "band" kernel
-// The generic pipeline re-fetches the activation tile once per filter tap (9x).  Here a workgroup that owns
-// 256 consecutive output pixels keeps, per 64-channel slice, the whole input BAND those pixels touch
-// (their image rows plus one halo row above and below, each row with a zero column left and right) in LDS
-// and reads the nine taps' B fragments from it at shifted addresses: activation traffic into LDS drops ~7x,
-// only the 9 small weight tiles of the slice are streamed.  Band rows are GLOBAL rows G = n*Ho + y, so the
-// fill needs no image logic; a tap whose row falls outside the pixel's own image is zeroed at fragment time.
-//   band ring : 2 stages x 512 band pixels x 64 B     (LDS-DMA, source-side XOR swizzle as everywhere)
-//   W ring    : 3 stages x BN x 64 B, one stage per (slice, tap) step, issued two steps ahead
-template <int BN_, int WM_, int WN_>
+// The generic pipeline re-fetches the activation tile once per filter tap (9x) and synchronises the workgroup
+// once per 64-deep K chunk.  Here a workgroup that owns BM consecutive output pixels keeps, per 64-channel
+// slice, the whole input BAND those pixels touch (their image rows plus one halo row above and below, each
+// row with a zero column left and right) in LDS and reads the nine taps' B fragments from it at shifted
+// addresses: activation traffic into LDS drops ~7x, only the weight tiles of the slice are streamed.  One
+// pipeline step covers a whole filter ROW (3 taps, K = 192): one barrier per 24 MFMAs per wave.  Band rows are
+// GLOBAL rows G = n*Ho + y, so the fill needs no image logic.
+//   band ring : BSTAGES x 4 planes x BAND_PX band pixels x 16 B: plane j holds channels 16j..16j+15 of every band
+//               pixel.  Consecutive pixels are 16 B apart, so a B-fragment read (16 lanes = 16 mostly consecutive
+//               pixels per LDS cycle) is conflict-free WITHOUT a swizzle and every (tap, k-half) address is
+//               base + immediate: the inner loop carries no address arithmetic.  The last 4 entries of each
+//               plane are zeros: taps whose row lies outside the pixel's image read those.
+//   W ring    : 3 stages x (3 taps x BN x 64 B), one stage per (slice, filter row) step, issued two steps ahead
+// Wave specialisation (NPROD > 0).  Measured on gfx950 (tools/ubench/mfma_rate.hip, HAWQ_DBG=128 stamps):
+// the matrix pipe serves the OLDEST ready wave of a SIMD first, an LDS-DMA issue blocks its wave for 60-150
+// cycles, and hipcc cannot overlap LDS reads with MFMAs once LDS-DMA is in the loop (see lds_read16).  With all
+// waves symmetric, a step cost ~3300 cycles for 1536 cycles of MFMA work per SIMD.  So NPROD extra "producer"
+// waves own every LDS-DMA issue and every vmcnt wait; the NW "consumer" waves only read fragments (hand
+// software-pipelined) and issue MFMAs, and the two kinds meet at the per-step barrier.
+template <int BM_, int BN_, int WM_, int WN_, int BAND_PX_, int BSTAGES_, int MINB_, int NPROD_>
 struct BandCfg {
-    static constexpr int BM = 256, BN = BN_, WM = WM_, WN = WN_;
-    static constexpr int NW = WM * WN, NT = NW * 64;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MINB = MINB_, NPROD = NPROD_;
+    static constexpr int NW = WM * WN;                        // consumer (MFMA) waves
+    static constexpr int NT = (NW + NPROD) * 64;
+    static constexpr int ND = NPROD > 0 ? NPROD : NW;         // waves that issue LDS-DMA
     static constexpr int PT = BM / WM / 32, CT = BN / WN / 32;
-    static constexpr int BAND_PX = 512;                       // band pixels per stage (upper bound, launcher-checked)
-    static constexpr int BAND_BYTES = BAND_PX * 64;
-    static constexpr int BP = BAND_PX / (16 * NW);            // LDS-DMA instructions per wave per band stage
-    static constexpr int WSTAGE = BN * 64;
-    static constexpr int WLOADERS = BN * 4 / 64;              // waves that issue the (single) W instruction of a step
-    static constexpr int LDS_BYTES = 2 * BAND_BYTES + 3 * WSTAGE;
-    static_assert(WLOADERS <= NW && BP >= 1, "tile shape");
+    static constexpr int BAND_PX = BAND_PX_, BSTAGES = BSTAGES_;  // band pixels per stage (launcher-checked bound)
+    static constexpr int PLANE = BAND_PX * 16, BAND_BYTES = 4 * PLANE;
+    static constexpr int BPI = BAND_PX / 16 / ND;             // band pieces (1 KiB LDS-DMA instructions) per issuing wave per stage
+    static constexpr int RG = BN / 16;                        // 16-row groups of a W tap tile
+    static constexpr int RPI = RG / ND, WPI = 3 * RPI;        // W row groups / pieces per issuing wave per step
+    static constexpr int WTAP = BN * 64, WSTAGE = 3 * WTAP;
+    static constexpr int LDS_BYTES = BSTAGES * BAND_BYTES + 3 * WSTAGE;
+    static_assert(RG % ND == 0 && (BAND_PX / 16) % ND == 0 && PT >= 1 && CT >= 1, "tile shape");
+    static_assert(BM * BN * 2 <= LDS_BYTES, "epilogue staging aliases the rings");
 };
 
 template <class C>
-__global__ __launch_bounds__(C::NT, 2) void conv3x3_band_kernel(const ConvP p) {
+__global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool prof = (p.dbg & 128) && p.dbgbuf;
+    const long long t_entry = prof ? (long long)__builtin_readcyclecounter() : 0;
     const int tiles_c = p.Cout / C::BN;
     const int nwg = ((p.M + C::BM - 1) / C::BM) * tiles_c;
     int wg = blockIdx.x;
@@ -836,52 +880,74 @@ __global__ __launch_bounds__(C::NT, 2) void conv3x3_band_kernel(const ConvP p) {
     const int tc = wg % tiles_c, tm = wg / tiles_c;
     const int m0 = tm * C::BM, c0 = tc * C::BN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wave_m = wave % C::WM, wave_c = wave / C::WM;
-    const int l31 = lane & 31, h = lane >> 5, lslot = lane & 3;
-    char *band = smem, *wring = smem + 2 * C::BAND_BYTES, *ctab_lds = smem + C::LDS_BYTES;
+    const bool consumer = wave < C::NW;
+    const bool issuer = C::NPROD > 0 ? !consumer : true;
+    const int dw = C::NPROD > 0 ? wave - C::NW : wave;       // index among the issuing waves
+    char *band = smem, *wring = smem + C::BSTAGES * C::BAND_BYTES, *ctab_lds = smem + C::LDS_BYTES;
     const char *zero = reinterpret_cast<const char *>(g_zero16);
-
-    if (wave < C::BN / 64)  // requant constants of this channel tile -> LDS, off the critical path
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.ctab + (size_t)(c0 + wave * 64 + lane) * 4),
-                                         (__attribute__((address_space(3))) void *)(ctab_lds + wave * 1024), 16, 0, 0);
 
     const int Wo = p.Wo, Wb = Wo + 2;
     const int G0 = m0 / Wo - 1;                 // global row held by band row 0
-    const int rows_total = p.N * p.Ho;
-    // ---- band fill bookkeeping: this lane's band pixel in each of the BP passes
-    const char *bsrc[C::BP];
-#pragma unroll
-    for (int i = 0; i < C::BP; ++i) {
-        const int bpx = (i * C::NW + wave) * 16 + (lane >> 2);
-        const int br = bpx / Wb, bc = bpx - br * Wb;
-        const int G = G0 + br, x = bc - 1;
-        const bool v = (unsigned)G < (unsigned)rows_total && (unsigned)x < (unsigned)Wo;
-        bsrc[i] = v ? (const char *)p.in + ((size_t)G * Wo + x) * p.Cin + ((lslot ^ ((bpx >> 2) & 3)) << 4) : nullptr;
-    }
     const int cchunks = p.Cin >> 6;
-    const int nsteps = 9 * cchunks;
-    const size_t wrow = (size_t)9 * p.Cin;
-    const char *wsrc = (const char *)p.wgt + (size_t)(c0 + wave * 16 + (lane >> 2)) * wrow +
-                       ((lslot ^ (((wave * 16 + (lane >> 2)) >> 2) & 3)) << 4);
-    const bool wloader = wave < C::WLOADERS;
+    const int nsteps = 3 * cchunks;             // step s = cc * 3 + kh
 
-    auto issue_band = [&](int cc) {
-        char *dst = band + (cc & 1) * C::BAND_BYTES + wave * 1024;
+    // ------------------------------------------------------------------ LDS-DMA side (issuing waves)
+    const char *bsrc[C::BPI];   // band piece j = i * ND + dw fills 64 pixels of plane (j & 3)
+    const char *wsrc[C::RPI];   // W row group r * ND + dw (16 rows), source-side swizzled like every operand tile
+    if (issuer) {
+        const int rows_total = p.N * p.Ho;
 #pragma unroll
-        for (int i = 0; i < C::BP; ++i) {
+        for (int i = 0; i < C::BPI; ++i) {
+            const int j = i * C::ND + dw;
+            const int bpx = (j >> 2) * 64 + lane;
+            const int br = bpx / Wb, bc = bpx - br * Wb;
+            const int G = G0 + br, x = bc - 1;
+            const bool v = (unsigned)G < (unsigned)rows_total && (unsigned)x < (unsigned)Wo && bpx < C::BAND_PX - 4;
+            bsrc[i] = v ? (const char *)p.in + ((size_t)G * Wo + x) * p.Cin + ((j & 3) << 4) : nullptr;
+        }
+#pragma unroll
+        for (int r = 0; r < C::RPI; ++r) {
+            const int row = (r * C::ND + dw) * 16 + (lane >> 2);
+            wsrc[r] = (const char *)p.wgt + (size_t)(c0 + row) * ((size_t)9 * p.Cin) + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+        }
+    }
+    auto issue_band = [&](int cc) {
+        char *dst = band + (C::BSTAGES > 1 ? (cc & 1) * C::BAND_BYTES : 0);
+#pragma unroll
+        for (int i = 0; i < C::BPI; ++i) {
+            const int j = i * C::ND + dw;
             const char *src = bsrc[i] ? bsrc[i] + (cc << 6) : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dst + i * (C::NW * 1024)), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dst + (j & 3) * C::PLANE + (j >> 2) * 1024), 16, 0, 0);
         }
     };
-    auto issue_w = [&](int s) {  // step s = cc * 9 + tap
-        if (!wloader) return;
-        const int cc = s / 9, tap = s - cc * 9;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc + (size_t)tap * p.Cin + (cc << 6)),
-                                         (__attribute__((address_space(3))) void *)(wring + (s % 3) * C::WSTAGE + wave * 1024), 16, 0, 0);
+    auto issue_w = [&](int s, int cc, int kh) {  // the 3 taps of filter row kh, channel slice cc -> ring stage s % 3
+        char *dst = wring + (s % 3) * C::WSTAGE + dw * 1024;
+        const size_t off = (size_t)(kh * 3) * p.Cin + (cc << 6);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int r = 0; r < C::RPI; ++r)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[r] + off + (size_t)kw * p.Cin),
+                                                 (__attribute__((address_space(3))) void *)(dst + kw * C::WTAP + r * (C::ND * 1024)), 16, 0, 0);
+    };
+    auto issue_step = [&](int s, int cc, int kh) {  // after the barrier of step s: ring stage (s+2)%3 and band stage (cc+1)&1 are free
+        if (C::BSTAGES > 1 && kh == 0 && cc + 1 < cchunks) issue_band(cc + 1);
+        if (s + 2 < nsteps) issue_w(s + 2, kh + 2 >= 3 ? cc + 1 : cc, kh + 2 >= 3 ? kh - 1 : kh + 2);
     };
 
-    // ---- per-lane output pixel geometry
+    if (issuer) {
+        if (dw < C::BN / 64)  // requant constants of this channel tile -> LDS (oldest load: landed before anything else)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.ctab + (size_t)(c0 + dw * 64 + lane) * 4),
+                                             (__attribute__((address_space(3))) void *)(ctab_lds + dw * 1024), 16, 0, 0);
+        issue_band(0);
+        issue_w(0, 0, 0);
+        issue_w(1, 0, 1);
+    }
+
+    // ------------------------------------------------------------------ MFMA side (consumer waves)
+    const int wave_m = wave % C::WM, wave_c = (wave / C::WM) % C::WN;
+    const int l31 = lane & 31, h = lane >> 5;
     int bp0[C::PT], yy[C::PT];
 #pragma unroll
     for (int q = 0; q < C::PT; ++q) {
@@ -890,9 +956,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv3x3_band_kernel(const ConvP p) {
         bp0[q] = (G - G0 - 1) * Wb + x;   // band pixel of tap (kh=0, kw=0)
         yy[q] = G % p.Ho;
     }
-    int wrw[C::CT];
+    int wofs[C::CT][2];  // A-fragment byte offsets inside a W tap tile (swizzled rows), k-halves 0/1
 #pragma unroll
-    for (int c = 0; c < C::CT; ++c) wrw[c] = wave_c * (C::CT * 32) + c * 32 + cperm(l31);
+    for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wofs[c][ks] = lds_off(wave_c * (C::CT * 32) + c * 32 + cperm(l31), 2 * ks + h);
 
     v16i acc[C::CT][C::PT];
 #pragma unroll
@@ -902,59 +970,107 @@ __global__ __launch_bounds__(C::NT, 2) void conv3x3_band_kernel(const ConvP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
 
-    issue_band(0);
-    issue_w(0);
-    if (nsteps > 1) issue_w(1);
-    const int myw = wloader ? 1 : 0;
-    int cc = 0, tap = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        // loads issued after W(s): W(s+1) if it exists, plus the band prefetch issued one or two steps ago
-        int allowed = (s + 1 < nsteps) ? myw : 0;
-        if ((tap == 1 || tap == 2) && cc + 1 < cchunks) allowed += C::BP;
-        switch (allowed) {
-            case 0: wait_vmcnt<0>(); break;
-            case 1: wait_vmcnt<1>(); break;
-            case C::BP: wait_vmcnt<C::BP>(); break;
-            default: wait_vmcnt<C::BP + 1>(); break;
-        }
+    const long long t_begin = prof ? (long long)__builtin_readcyclecounter() : 0;
+    // Barrier #0: band(0), W(0), W(1) visible.  Barrier #(s+1) closes step s; BEFORE it the issuing waves have
+    // seen W(s+2) (and a band prefetch) land, so that the MFMA waves may request the first fragments of step
+    // s+1 already at the end of step s and cross the barrier with their LDS reads in flight (the exposed
+    // barrier + first-fetch latency was ~500 of ~2000 cycles per step).  Ring stage (s+2)%3 was last read in
+    // step s-1, i.e. before barrier #s, after which W(s+2) is issued.
+    if (C::NPROD > 0 && !consumer) {
+        int cc = 0, kh = 0;
+        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (s + 2 < nsteps) issue_w(s + 2);
-        if (tap == 0 && cc + 1 < cchunks) issue_band(cc + 1);
-
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const char *bst = band + (cc & 1) * C::BAND_BYTES, *wst = wring + (s % 3) * C::WSTAGE;
-        const int toff = kh * Wb + kw;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int slot = 2 * ks + h;
-            v4i wf[C::CT], af[C::PT];
-#pragma unroll
-            for (int c = 0; c < C::CT; ++c) wf[c] = *reinterpret_cast<const v4i *>(wst + lds_off(wrw[c], slot));
+        for (int s = 0; s < nsteps; ++s) {
+            if (!(p.dbg & 1)) issue_step(s, cc, kh);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (++kh == 3) kh = 0, ++cc;
+        }
+    } else {
+        if (C::NPROD > 0) __builtin_amdgcn_s_setprio(2);  // MFMA waves win issue arbitration against the producers
+        const bool early = wave < C::NW / 2;  // waves w and w + NW/2 share a SIMD (only used when NPROD == 0)
+        unsigned ap[C::PT], wp[C::CT][2];
+        // operand bases of step (s, cc, kh); everything inside the batches is base + compile-time immediate
+        auto bases = [&](int s, int cc, int kh) {
+            const char *bst = band + (C::BSTAGES > 1 ? (cc & 1) * C::BAND_BYTES : 0) + h * C::PLANE, *wst = wring + (s % 3) * C::WSTAGE;
 #pragma unroll
             for (int q = 0; q < C::PT; ++q) {
-                const int bp = bp0[q] + toff;
-                v4i a = *reinterpret_cast<const v4i *>(bst + bp * 64 + ((slot ^ ((bp >> 2) & 3)) << 4));
-                if ((unsigned)(yy[q] + kh - 1) >= (unsigned)p.Ho) a = v4i{0, 0, 0, 0};  // row of another image / padding
-                af[q] = a;
+                const bool rowok = (unsigned)(yy[q] + kh - 1) < (unsigned)p.Ho;  // else: another image's row / padding -> zeros
+                ap[q] = lds_addr(bst) + (rowok ? bp0[q] + kh * Wb : C::BAND_PX - 4) * 16;
             }
 #pragma unroll
             for (int c = 0; c < C::CT; ++c)
 #pragma unroll
-                for (int q = 0; q < C::PT; ++q)
-                    acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[c], af[q], acc[c][q], 0, 0, 0);
-        }
-        if (++tap == 9) {
-            tap = 0;
-            ++cc;
-        }
+                for (int ks = 0; ks < 2; ++ks) wp[c][ks] = lds_addr(wst) + wofs[c][ks];
+        };
+        // 6 batches per step (tap kw = b / 2, k-half ks = b % 2) of CT x PT MFMAs, software-pipelined by hand: the
+        // fragments of the next batch are requested from LDS before the MFMAs of the current one are issued.
+        v4i wf[2][C::CT], af[2][C::PT];
+#define BAND_FETCH(B, BUF)                                                                                        \
+    if (!(p.dbg & 4)) {                                                                                           \
+        _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                         \
+            wf[BUF][c] = lds_read16<((B) >> 1) * C::WTAP>(wp[c][(B) & 1]);                                        \
+        _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                                         \
+            af[BUF][q] = lds_read16<((B) >> 1) * 16 + ((B) & 1) * (2 * C::PLANE)>(ap[q]);                         \
     }
+#define BAND_MMA(B)                                                                                               \
+    {                                                                                                             \
+        _Pragma("unroll") for (int c = 0; c < C::CT; ++c) pin(wf[(B) & 1][c]);                                    \
+        _Pragma("unroll") for (int q = 0; q < C::PT; ++q) pin(af[(B) & 1][q]);                                    \
+        _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                         \
+            _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                                     \
+                acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[(B) & 1][c], af[(B) & 1][q], acc[c][q], 0, 0, 0); \
+    }
+#define BAND_BATCH(B)                                                                                             \
+    {                                                                                                             \
+        BAND_FETCH((B) + 1, ((B) + 1) & 1)                                                                        \
+        wait_lgkm<C::CT + C::PT>();                                                                               \
+        BAND_MMA(B)                                                                                               \
+    }
+        int cc = 0, kh = 0;
+        if (C::NPROD == 0) wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        bases(0, 0, 0);
+        BAND_FETCH(0, 0)
+        for (int s = 0; s < nsteps; ++s) {
+            BAND_BATCH(0)
+            if (C::NPROD == 0 && early && !(p.dbg & 1)) issue_step(s, cc, kh);
+            BAND_BATCH(1)
+            BAND_BATCH(2)
+            BAND_BATCH(3)
+            if (C::NPROD == 0 && !early && !(p.dbg & 1)) issue_step(s, cc, kh);
+            BAND_BATCH(4)
+            if (++kh == 3) kh = 0, ++cc;
+            if (s + 1 < nsteps) {  // first fragments of the next step (its operands are visible since the previous barrier)
+                bases(s + 1, cc, kh);
+                BAND_FETCH(0, 0)
+                wait_lgkm<C::CT + C::PT>();
+            } else {
+                wait_lgkm<0>();
+            }
+            BAND_MMA(5)
+            if (C::NPROD == 0) wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+#undef BAND_FETCH
+#undef BAND_MMA
+#undef BAND_BATCH
+        if (C::NPROD > 0) __builtin_amdgcn_s_setprio(0);
+    }
+    const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
     v16i dummy[1][1];
-    epilogue_fast<C, HAWQ_EPI_REQUANT, false>(p, acc, dummy, m0, c0, smem, smem, ctab_lds);
+    epilogue_fast<C, HAWQ_EPI_REQUANT, false>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    if (prof && blockIdx.x == 8 && t == 0) {
+        p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
+        p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
+    }
 }
 
-using B0 = BandCfg<64, 4, 1>;    // Cout == 64 layers (stage 1): 4 waves x (64 px x 64 ch)
-using B1 = BandCfg<128, 4, 2>;   // 8 waves x (64 px x 64 ch)
+using B0 = BandCfg<256, 64, 4, 1, 512, 1, 2, 0>;    // Cin == Cout == 64 (stage 1): 4 waves x (64 px x 64 ch), 2 workgroups per CU
+using B1 = BandCfg<256, 128, 4, 2, 512, 2, 1, 8>;   // 8 MFMA waves x (64 px x 64 ch) + 8 producer waves (LDS-DMA ingest scales with the issuing waves)
+using B2 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8>;   // 8 MFMA waves x (64 px x 32 ch) + 8 producers: twice the workgroups for 14x14 / 7x7
+constexpr int NUM_BAND_TILES = 3;
 
 using T0 = Cfg<128, 128, 2, 2, 3>;
 using T1 = Cfg<256, 64, 4, 1, 3>;
@@ -1028,7 +1144,8 @@ int pick_tile(int M, int Cout, bool dual) {
 
 }  // namespace
 
-extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + 2; }  // + the two 3x3 band kernels
+extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES; }  // the 3x3 band kernels are the last ids
+extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES; }
 
 extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     HAWQ_REQUIRE(a != nullptr, "hawq_conv2d: null args");
@@ -1076,6 +1193,10 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.ctab = a->ctab, p.ctab_id = a->ctab_id;
     static const int dbg_env = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
     p.dbg = a->fast_tables ? dbg_env : 0;  // ablations only touch the fused-plan launches
+    p.dbgbuf = nullptr;
+    static long long *dbg_dev = nullptr;
+    if ((p.dbg & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
+    if (p.dbg & 128) p.dbgbuf = dbg_dev;
     const bool fast = a->fast_tables != 0;
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
@@ -1130,23 +1251,35 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             HAWQ_REQUIRE(false, "hawq_conv2d: unknown epilogue %d", a->epilogue);
     }
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
-    if (tile >= NUM_TILES && tile < NUM_TILES + 2) {
+    if (tile >= NUM_TILES && tile < NUM_TILES + NUM_BAND_TILES) {
         // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 REQUANT layers only
-        const int bn = tile == NUM_TILES ? 64 : 128;
-        const int wo = p.Wo, band_rows = (256 + wo - 1) / wo + 1 + 2;
+        struct BandInfo { KernelFn fn; int bm, bn, band_px, bstages, lds, nt; };
+#define BAND_ENTRY(B) {conv3x3_band_kernel<B>, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
+        static const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2)};
+        const BandInfo &bi = kBand[tile - NUM_TILES];
+        const int bn = bi.bn;
+        const int wo = p.Wo, band_rows = (bi.bm + wo - 1) / wo + 1 + 2;
         const bool ok = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && !dual && fast &&
                         a->epilogue == HAWQ_EPI_REQUANT && a->in_bits == 8 && a->w_bits == 8 && p.Cout % bn == 0 &&
-                        band_rows * (wo + 2) <= 512 && a->out_q;
+                        band_rows * (wo + 2) <= bi.band_px - 4 && a->out_q && (bi.bstages > 1 || a->Cin == 64);
         HAWQ_REQUIRE(ok, "hawq_conv2d: tile %d (3x3 band kernel) does not apply to this layer", a->tile);
-        static const bool band_attrs = hipFuncSetAttribute((const void *)conv3x3_band_kernel<B0>, hipFuncAttributeMaxDynamicSharedMemorySize, B0::LDS_BYTES + 4096) == hipSuccess &&
-                                       hipFuncSetAttribute((const void *)conv3x3_band_kernel<B1>, hipFuncAttributeMaxDynamicSharedMemorySize, B1::LDS_BYTES + 4096) == hipSuccess;
+        static const bool band_attrs = [] {
+            bool good = true;
+            for (const BandInfo &b : kBand)
+                good &= hipFuncSetAttribute((const void *)b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
+            return good;
+        }();
         HAWQ_REQUIRE(band_attrs, "hawq_conv2d: hipFuncSetAttribute failed for the band kernels");
-        const int grid_b = ((p.M + 255) / 256) * (p.Cout / bn);
-        if (bn == 64)
-            hipLaunchKernelGGL(conv3x3_band_kernel<B0>, dim3(grid_b), dim3(B0::NT), B0::LDS_BYTES + B0::BN * 16, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(conv3x3_band_kernel<B1>, dim3(grid_b), dim3(B1::NT), B1::LDS_BYTES + B1::BN * 16, (hipStream_t)stream, p);
+        const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bn);
+        hipLaunchKernelGGL(bi.fn, dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
         HAWQ_CHECK_HIP(hipGetLastError());
+        if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
+            long long hbuf[4];
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            (void)hipMemcpy(hbuf, p.dbgbuf, sizeof(hbuf), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[band bm=%d bn=%d M=%d Cin=%d Cout=%d] steps %lld: prologue %lld | K loop %lld | epilogue %lld cycles (wave 0 of workgroup 8, s_memtime)\n",
+                    bi.bm, bn, p.M, p.Cin, p.Cout, hbuf[3], hbuf[0], hbuf[1], hbuf[2]);
+        }
         return 0;
     }
     HAWQ_REQUIRE(tile >= 0 && tile < NUM_TILES, "hawq_conv2d: bad tile id %d", a->tile);

@@ -110,6 +110,9 @@ typedef struct hawq_conv_args {
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
 int hawq_conv2d_num_tiles(void);
+/* The LAST hawq_conv2d_num_band_tiles() tile ids are the 3x3/stride-1/pad-1 "band" kernels (fast-contract
+ * int8 REQUANT layers only; hawq_conv2d refuses them for any other layer).  All other ids take any layer. */
+int hawq_conv2d_num_band_tiles(void);
 
 /* QuantAct input case (quant_modules.py:271-274; quant_utils.py:73-97, 237-258):
  * q = clamp(rint(inv_scale * x), lo, hi); fp32 NCHW [N][3][H][W] -> int8 NHWC4 with a zero

@@ -109,7 +109,7 @@ def test_conv_raw_accumulators(lib, orc, shape, bits):
     rng = np.random.default_rng(hash((shape, bits)) % 2 ** 32)
     x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
     ref = orc.conv2d(x, wt, b, stride, pad)
-    for tile in range(0, lib.load().hawq_conv2d_num_tiles() + 1 - 2):  # the last two ids are the 3x3 band kernels
+    for tile in range(0, lib.load().hawq_conv2d_num_tiles() + 1 - lib.load().hawq_conv2d_num_band_tiles()):  # the last ids are the 3x3 band kernels
         a, keep = conv_args(lib, x, wt, b, stride, pad, *bits, tile=tile)
         out = torch.full((ref.size,), -7, dtype=torch.int32, device='cuda')
         a.epilogue, a.out_acc = lib.EPI_RAW, out.data_ptr()
@@ -170,9 +170,9 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
 
 
 @pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (9, 7, 7, 128, 128),
-                                   (1, 14, 20, 64, 192), (2, 9, 30, 192, 64)])
+                                   (1, 14, 20, 64, 192), (2, 9, 30, 192, 128), (7, 7, 7, 512, 128), (1, 3, 5, 64, 64)])
 def test_conv3x3_band_kernels(lib, orc, shape):
-    """The LDS-band 3x3 kernels (tile ids N-1, N) vs the oracle: all ResNet50 spatial sizes, several images per
+    """The LDS-band 3x3 kernels (the last tile ids) vs the oracle: all ResNet50 spatial sizes, several images per
     workgroup, ragged last tile, rectangular maps; both ReLU settings; int8 and hawq4 outputs."""
     from hawq_amd.packing import pack_ctab
     from hawq_amd.quant_utils import tables_are_fast
@@ -182,10 +182,20 @@ def test_conv3x3_band_kernels(lib, orc, shape):
     acc = orc.conv2d(x, wt, b, 1, 1)
     m, e = rand_tables(rng, cout, 2e-5, 3e-4)
     assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
-    ntiles = lib.load().hawq_conv2d_num_tiles()
+    ntiles, nband = lib.load().hawq_conv2d_num_tiles(), lib.load().hawq_conv2d_num_band_tiles()
+    # (pixels per workgroup, channel tile, band pixels per LDS stage, needs Cin == 64) of the band tiles, in id order
+    geom = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False)]
+    assert nband == len(geom)
     ran = 0
-    for tile in (ntiles - 1, ntiles):
-        if cout % (64 if tile == ntiles - 1 else 128):
+    for tile, (bm, bn, band_px, cin64) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
+        applies = cout % bn == 0 and ((bm + w - 1) // w + 3) * (w + 2) <= band_px - 4 and (cin == 64 or not cin64)
+        if not applies:
+            a, keep = conv_args(lib, x, wt, b, 1, 1, 8, 8, tile=tile)
+            keep.update(ctab=dev(pack_ctab(b, m, e)), m=dev(m), e=dev(e))
+            out = torch.zeros(acc.size, dtype=torch.uint8, device='cuda')
+            a.epilogue, a.relu, a.m, a.e, a.ctab, a.fast_tables = lib.EPI_REQUANT, 1, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), 1
+            a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), 8, -128, 127
+            assert lib.load().hawq_conv2d(C.byref(a), None) != 0   # refused, not mis-computed
             continue
         for relu, out_bits, (lo, hi) in ((1, 8, (-128, 127)), (0, 8, (-128, 127)), (1, 4, (0, 15))):
             a, keep = conv_args(lib, x, wt, b, 1, 1, 8, 8, tile=tile)
