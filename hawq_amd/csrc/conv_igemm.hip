@@ -49,9 +49,10 @@ struct ConvP {
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
 
-template <int BM_, int BN_, int WM_, int WN_, int NS_, int KSUB_ = 1>
+template <int BM_, int BN_, int WM_, int WN_, int NS_, int KSUB_ = 1, int MINB_ = 2>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int MINB = MINB_;       // workgroups per CU the register allocation must allow
     static constexpr int NS = NS_;           // LDS ring stages of the asynchronous (global_load_lds) pipeline
     static constexpr int KSUB = KSUB_;       // 64-channel sub-chunks per ring stage (one barrier per stage)
     static constexpr int NW = WM_ * WN_;     // waves per workgroup (4 or 8)
@@ -758,7 +759,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 }
 
 template <class C, int EPI, bool DUAL, int BITS, int BITS2>
-__global__ __launch_bounds__(C::NT, 2) void conv_kernel(const ConvP p) {
+__global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
     // each XCD a contiguous run of pixel tiles that share the same weight tile in its L2.
@@ -1086,7 +1087,13 @@ using T6 = Cfg<128, 64, 2, 2, 3, 2>;
 using T7 = Cfg<128, 128, 2, 4, 3>;
 using T8 = Cfg<128, 128, 2, 4, 3, 2>;
 using T9 = Cfg<256, 128, 4, 2, 3>;
-constexpr int NUM_TILES = 10;
+// shallow rings for the short-K, epilogue-heavy layers (1x1 expand + residual): less LDS per workgroup = more
+// workgroups per CU (4 / 5 instead of 3), whose load, epilogue-VALU and store phases then overlap
+using T10 = Cfg<64, 64, 2, 2, 3, 1, 6>;
+using T11 = Cfg<64, 64, 2, 2, 2, 1, 6>;
+using T12 = Cfg<128, 64, 2, 2, 2, 1, 3>;
+using T13 = Cfg<128, 128, 2, 4, 2, 1, 2>;
+constexpr int NUM_TILES = 14;
 
 typedef void (*KernelFn)(const ConvP);
 // single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
@@ -1112,7 +1119,8 @@ struct TileInfo {
     }
 const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0, 0), TILE_ENTRY(T1, 1), TILE_ENTRY(T2, 2), TILE_ENTRY(T3, 3),
                                     TILE_ENTRY(T4, 0), TILE_ENTRY(T5, 2), TILE_ENTRY(T6, 3),
-                                    TILE_ENTRY(T7, 7), TILE_ENTRY(T8, 7), TILE_ENTRY(T9, 9)};
+                                    TILE_ENTRY(T7, 7), TILE_ENTRY(T8, 7), TILE_ENTRY(T9, 9),
+                                    TILE_ENTRY(T10, 10), TILE_ENTRY(T11, 11), TILE_ENTRY(T12, 12), TILE_ENTRY(T13, 13)};
 
 // kernels whose staged epilogue needs more than the default 64 KiB of dynamic LDS
 bool raise_lds_limits() {
