@@ -184,7 +184,8 @@ def main():
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
                        "residual_uint16_overflow": overflow,
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}",
-                       "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values())},
+                       "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
+                       "concurrent_sub_batches": eng.chains},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "one hipGraph launch = whole forward of one batch",

@@ -94,7 +94,7 @@ class IntegerEngine:
     instead of re-deriving them from the float parameters."""
 
     def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
-                 keep_accumulators: bool = False, fast: bool = True, autotune: bool = True, chains: int = 1,
+                 keep_accumulators: bool = False, fast: bool = True, autotune: bool = True, chains: int = 0,
                  _parent=None):
         if _parent is not None:  # a chain of a multi-chain engine: shares parameters, owns stream + buffers
             self.__dict__.update({k: v for k, v in _parent.__dict__.items()
@@ -120,8 +120,11 @@ class IntegerEngine:
         self.autotune = autotune  # pick each conv launch's tile configuration by timing it once per batch shape
         self.tile_choice = {}
         # chains > 1: the batch is split into independent sub-batches whose launch chains run on separate
-        # streams inside ONE hipGraph, so that one chain's kernel tails / launch gaps overlap the other's work
-        self.chains = 1 if keep_accumulators else max(1, int(os.environ.get("HAWQ_CHAINS", chains)))
+        # streams inside ONE hipGraph, so that one chain's kernel tails / prologues / epilogues overlap the
+        # other's work (the late layers launch fewer workgroups than there are CUs).  0 = choose 1, 2 or 3 by
+        # timing the captured graph once per batch shape (HAWQ_CHAINS overrides).
+        self.chains_req = 1 if keep_accumulators else max(0, int(os.environ.get("HAWQ_CHAINS", chains)))
+        self.chains = max(1, self.chains_req)
         self.subs = []
         self.stream = torch.cuda.Stream(device=self.dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -249,8 +252,47 @@ class IntegerEngine:
         return torch.empty(n, dtype=dtype, device=self.dev)
 
     def _build(self, N, H, W, x_view=None, logits_view=None):
-        """Allocate activation buffers for batch N and record the launch list."""
+        """Allocate activation buffers for batch N and record the launch list (choosing the chain count first
+        when it was left open)."""
+        if x_view is None and getattr(self, "chains_req", 1) == 0 and self.use_graph and self.autotune:
+            timing = {}
+            for c in ((1, 2, 3) if N >= 48 else (1,)):
+                self.chains = c
+                self._build_chains(N, H, W)
+                timing[c] = self._time_graph() if N >= 48 else 0.0
+                self._drop_graph()
+            self.chains = min(timing, key=timing.get)
+            self.chain_timing_ms = timing
+        self._build_chains(N, H, W, x_view, logits_view)
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            _lib.call("hawq_graph_destroy", self._graph)
+            self._graph = None
+
+    def _time_graph(self, reps: int = 8) -> float:
+        """ms per replay of the captured graph on whatever the input buffer holds (tuning only)."""
+        self.x_in.zero_()
+        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+        _lib.call("hawq_event_create", C.byref(e0))
+        _lib.call("hawq_event_create", C.byref(e1))
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):
+                self.run_resident()
+            _lib.call("hawq_event_record", e0, self.stream.cuda_stream)
+            for _ in range(reps):
+                self.run_resident()
+            _lib.call("hawq_event_record", e1, self.stream.cuda_stream)
+        torch.cuda.synchronize(self.dev)
+        _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
+        _lib.call("hawq_event_destroy", e0)
+        _lib.call("hawq_event_destroy", e1)
+        self.flags.zero_()
+        return ms.value / reps
+
+    def _build_chains(self, N, H, W, x_view=None, logits_view=None):
         P, dev = self.P, self.dev
+        self._drop_graph()
         if self.chains > 1 and N >= 2 * self.chains:
             self.x_in = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
             self.logits = torch.empty(N, P['fc']['nout'], dtype=torch.float32, device=dev)

@@ -95,6 +95,28 @@ def test_network_matches_oracle_on_unseen_inputs(arch, scheme, batch):
     print(f"{arch} {scheme}: max un-clamped residual {mx}")
 
 
+def test_concurrent_sub_batches_are_bit_identical():
+    """The engine may split a batch into 2-3 sub-batches that run concurrently inside one hipGraph (chosen by
+    timing at batch >= 48, or forced): logits must not depend on the split (uneven splits included)."""
+    from hawq_amd.api import calibrate
+    from hawq_amd.engine import IntegerEngine
+    from hawq_amd.skeleton import synthetic_images
+    model = H.build_model("resnet50", "uniform8")
+    calibrate(model, _images().cuda())
+    x = (synthetic_images(50, seed=11) * 1.3).cuda()
+    ref = IntegerEngine(model, chains=1)(x).clone()
+    for chains in (2, 3, 0):
+        eng = IntegerEngine(model, chains=chains)
+        y = eng(x).clone()
+        assert torch.equal(y, ref), chains
+        assert torch.equal(eng(x), ref), chains   # graph replay
+        if chains == 0:
+            assert eng.chains in (1, 2, 3) and set(eng.chain_timing_ms) == {1, 2, 3}
+        else:
+            assert eng.chains == chains and len(eng.subs) == chains
+        assert not eng.overflowed()
+
+
 def test_model_call_uses_fused_engine_and_cpu_raises():
     from hawq_amd.api import calibrate
     model = H.build_model("resnet18", "uniform8")
