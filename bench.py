@@ -197,7 +197,9 @@ def main():
             tot = sum(ms for _, ms in ops)
             rows = {r["name"]: r for r in roofline.layer_table(args.arch, args.scheme)}
             top = sorted(ops, key=lambda t: -t[1])[:8]
+            # eager launches timed one by one; with concurrent sub-batches this is sub-batch 0 alone
             out["roofline"]["eager_sum_ms"] = round(tot, 4)
+            out["roofline"]["eager_sum_batch"] = args.batch if eng.chains == 1 else eng.subs[0]._batch[0]
             out["roofline"]["top_launches"] = [{"name": n, "ms": round(ms, 4)} for n, ms in top]
             if args.per_op:
                 write_per_op(args.per_op, ops, rows, args.batch)

@@ -414,7 +414,15 @@ __global__ __launch_bounds__(256) void requant_residual_kernel(const void *__res
 }
 
 // ------------------------------------------------------------------ global average pool + QuantAct
-// thread = one (n, c): strided over HW (tiny tensor: N*49*C elements)
+// trunc(sum/HW + 0.01) in exact rationals (== floor(sum/HW) for sum >= 0), then the next QuantAct's table
+__device__ __forceinline__ void avgpool_finish(long long s, int HW, int i, int8_t *out, int32_t *pooled, int mq, int eq,
+                                               int q_lo, int q_hi) {
+    const long long p = (100 * s + HW) / (100ll * HW);
+    if (pooled) pooled[i] = (int32_t)p;
+    out[i] = (int8_t)clampi(dyadic_rne((int32_t)p, mq, eq), q_lo, q_hi);
+}
+
+// general form: thread = one (n, c), strided over HW (int32 residuals, odd channel counts)
 __global__ __launch_bounds__(256) void avgpool_requant_kernel(const void *__restrict__ in, int in_bits, int N, int HW,
                                                               int C, int8_t *__restrict__ out,
                                                               int32_t *__restrict__ pooled, int mq, int eq, int q_lo,
@@ -427,10 +435,32 @@ __global__ __launch_bounds__(256) void avgpool_requant_kernel(const void *__rest
         const size_t idx = ((size_t)n * HW + k) * C + c;
         s += in_bits == 16 ? (long long)((const uint16_t *)in)[idx] : (long long)((const int32_t *)in)[idx];
     }
-    // trunc(sum/HW + 0.01) in exact rationals (== floor(sum/HW) for sum >= 0)
-    const long long p = (100 * s + HW) / (100ll * HW);
-    if (pooled) pooled[i] = (int32_t)p;
-    out[i] = (int8_t)clampi(dyadic_rne((int32_t)p, mq, eq), q_lo, q_hi);
+    avgpool_finish(s, HW, i, out, pooled, mq, eq, q_lo, q_hi);
+}
+
+// uint16 residuals, C % 256 == 0: workgroup = (image, 256 channels); lane group g = t / 32 takes pixels g, g+8, ...
+// with 16-byte loads (8 channels per lane: a wave instruction reads two full 512-byte pixel rows), partial sums
+// meet in LDS.  HW * 65535 < 2^31 is checked by the launcher.
+__global__ __launch_bounds__(256) void avgpool_requant_u16_kernel(const uint16_t *__restrict__ in, int HW, int C,
+                                                                  int8_t *__restrict__ out, int32_t *__restrict__ pooled,
+                                                                  int mq, int eq, int q_lo, int q_hi) {
+    __shared__ int part[8][256];
+    const int t = threadIdx.x, cg = t & 31, g = t >> 5;
+    const int n = blockIdx.x / (C >> 8), c0 = (blockIdx.x % (C >> 8)) << 8;
+    int s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t *base = in + (size_t)n * HW * C + c0 + cg * 8;
+    for (int k = g; k < HW; k += 8) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + (size_t)k * C);
+        s[0] += v.x & 0xffff, s[1] += v.x >> 16, s[2] += v.y & 0xffff, s[3] += v.y >> 16;
+        s[4] += v.z & 0xffff, s[5] += v.z >> 16, s[6] += v.w & 0xffff, s[7] += v.w >> 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[g][cg * 8 + j] = s[j];
+    __syncthreads();
+    long long tot = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tot += part[j][t];
+    avgpool_finish(tot, HW, n * C + c0 + t, out, pooled, mq, eq, q_lo, q_hi);
 }
 
 inline int grid_for(long long work_items) {
@@ -504,8 +534,12 @@ extern "C" int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, 
     HAWQ_REQUIRE(in && out, "hawq_avgpool_requant: null pointer");
     HAWQ_REQUIRE(in_bits == 16 || in_bits == 32, "hawq_avgpool_requant: in_bits 16/32");
     HAWQ_REQUIRE(N > 0 && HW > 0 && C > 0, "hawq_avgpool_requant: bad geometry");
-    hipLaunchKernelGGL(avgpool_requant_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, in,
-                       in_bits, N, HW, C, out, pooled_out, mq, eq, q_lo, q_hi);
+    if (in_bits == 16 && C % 256 == 0 && HW <= 32768 && (reinterpret_cast<size_t>(in) & 15) == 0)
+        hipLaunchKernelGGL(avgpool_requant_u16_kernel, dim3(N * (C / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint16_t *)in, HW, C, out, pooled_out, mq, eq, q_lo, q_hi);
+    else
+        hipLaunchKernelGGL(avgpool_requant_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, in,
+                           in_bits, N, HW, C, out, pooled_out, mq, eq, q_lo, q_hi);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -474,6 +474,15 @@ class IntegerEngine:
         _lib.call("hawq_event_create", C.byref(e0))
         _lib.call("hawq_event_create", C.byref(e1))
         ms = C.c_float()
+        fixed = os.environ.get("HAWQ_TILES")  # dotted list as printed by bench.py: replay a recorded choice, no timing
+        if fixed:
+            ids = [int(v) for v in fixed.split(".")]
+            if len(ids) != len(self._conv_args):
+                raise ValueError(f"HAWQ_TILES lists {len(ids)} tiles, the plan has {len(self._conv_args)} conv launches")
+            for name, a, tid in zip(self._conv_names, self._conv_args, ids):
+                a.tile = tid
+                self.tile_choice[name] = tid
+            return
         with torch.cuda.stream(self.stream):
             self._launch_all()  # every buffer holds valid data
             for name, a in [(n, k) for n, k in zip(self._conv_names, self._conv_args)]:

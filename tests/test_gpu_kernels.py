@@ -382,11 +382,14 @@ def test_fused_stem_matches_unfused_semantics(lib, orc, shape):
 
 
 @pytest.mark.parametrize("res_bits", [16, 32])
-def test_avgpool_requant(lib, orc, res_bits):
+@pytest.mark.parametrize("c", [512, 320])
+def test_avgpool_requant(lib, orc, res_bits, c):
+    """c = 512 takes the 16-byte-load uint16 kernel, c = 320 / int32 residuals the general one."""
     from hawq_amd.quant_utils import requant_table
     rng = np.random.default_rng(21)
-    n, c = 3, 512
+    n = 3
     x = rng.integers(0, 45000, (n, c, 7, 7)).astype(np.int64)
+    x[1, 7] = 65535
     x[0, 0] = 3
     x[0, 1] = 5
     x[0, 1, 6, 6] = 4
