@@ -97,23 +97,29 @@ def cpu_baseline(model, x, gpu_logits, sample=16):
                        f"the reference path, {dt:.1f} s)", gpu_logits_bit_equal=parity)
 
 
+def launch_model(name, rows, batch):
+    """(algorithmic bytes, MACs) of one launch for `batch` images: the canonical per-layer model
+    (hawq_amd/roofline.py:layer_table) summed over the layers the launch covers."""
+    parts = []
+    base = name.split("+")[0]
+    if base in rows:
+        parts.append(rows[base])
+    if name.endswith("+identity"):
+        parts.append(rows[base.rsplit(".", 1)[0] + ".quant_identity_convbn"])
+    if name in ("hawq_quantize_input", "hawq_stem_fused"):
+        parts.append(rows["quant_input"])
+    if name in ("hawq_stem_conv7", "hawq_stem_fused"):
+        parts += [r for k, r in rows.items() if k.startswith("quant_init")]
+    if name == "hawq_avgpool_requant":
+        parts.append(rows["final_pool+quant_act_output"])
+    return (sum(r["act_bytes"] for r in parts) * batch + sum(r["weight_bytes"] for r in parts),
+            sum(r["macs"] for r in parts) * batch)
+
+
 def write_per_op(path, ops, rows, batch):
     """Per-launch table: measured ms vs the canonical byte/MAC model of the layers each launch covers."""
     def model(name):
-        parts = []
-        base = name.split("+")[0]
-        if base in rows:
-            parts.append(rows[base])
-        if name.endswith("+identity"):
-            parts.append(rows[base.rsplit(".", 1)[0] + ".quant_identity_convbn"])
-        if name == "hawq_quantize_input":
-            parts.append(rows["quant_input"])
-        if name == "hawq_stem_conv7":
-            parts += [r for k, r in rows.items() if k.startswith("quant_init")]
-        if name == "hawq_avgpool_requant":
-            parts.append(rows["final_pool+quant_act_output"])
-        return (sum(r["act_bytes"] for r in parts) * batch + sum(r["weight_bytes"] for r in parts),
-                sum(r["macs"] for r in parts) * batch)
+        return launch_model(name, rows, batch)
     lines = ["| launch | ms | model MB | GB/s | % of 8 TB/s | GMAC | TOPS |", "|---|---|---|---|---|---|---|"]
     for n, ms in ops:
         b, mc = model(n)
@@ -183,7 +189,7 @@ def main():
                        "scheme": args.scheme, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
                        "residual_uint16_overflow": overflow,
-                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}",
+                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "shift_free_requant_launches": eng.n_k0,
                        "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
                        "concurrent_sub_batches": eng.chains},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
@@ -201,6 +207,14 @@ def main():
             out["roofline"]["eager_sum_ms"] = round(tot, 4)
             out["roofline"]["eager_sum_batch"] = args.batch if eng.chains == 1 else eng.subs[0]._batch[0]
             out["roofline"]["top_launches"] = [{"name": n, "ms": round(ms, 4)} for n, ms in top]
+            # the single most expensive kernel launch against its own byte / MAC model
+            dn, dms = top[0]
+            db, dm = launch_model(dn, rows, out["roofline"]["eager_sum_batch"])
+            out["roofline"]["dominant_launch"] = {
+                "name": dn, "ms": round(dms, 4), "batch": out["roofline"]["eager_sum_batch"],
+                "algorithmic_bytes": db, "achieved_GBps": round(db / dms / 1e6, 1),
+                "hbm_frac": round(db / dms / 1e6 / roofline.HBM_PEAK_GBS, 4),
+                "mfma_frac": round(2 * dm / (dms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)}
             if args.per_op:
                 write_per_op(args.per_op, ops, rows, args.batch)
         if not args.no_cpu_baseline and world == 1:

@@ -70,6 +70,19 @@ __device__ __forceinline__ int32_t dyadic_nt(int32_t v, const DyNt &c) {
     const long long t = (long long)(v << c.k) * (long long)c.m + c.add;
     return (int)(t >> 32) >> c.s;
 }
+// K0: the host additionally guarantees k == 0 for this table (true for every conv table whose e is >= 33 without
+// lifting, i.e. whenever the requant ratio is below 2^-2): one VALU instruction less per element
+template <bool K0>
+__device__ __forceinline__ int32_t dyadic_nt_k(int32_t v, const DyNt &c) {
+    const long long t = (long long)(K0 ? v : (v << c.k)) * (long long)c.m + c.add;
+    return (int)(t >> 32) >> c.s;
+}
+// clamp(v, lo, hi) for lo <= hi in one instruction
+__device__ __forceinline__ int32_t med3i(int32_t v, int32_t lo, int32_t hi) {
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
 
 __device__ __forceinline__ int32_t clampi(int32_t v, int32_t lo, int32_t hi) {
     return v < lo ? lo : (v > hi ? hi : v);

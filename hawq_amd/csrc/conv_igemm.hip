@@ -45,6 +45,7 @@ struct ConvP {
     int ldo, n_valid;
     int32_t *flags;
     const int32_t *ctab, *ctab_id;
+    int k0;   // fast path: every pre-shift of ctab / ctab_id / (mq, eq) is 0
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
@@ -607,7 +608,7 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
     }
 }
 
-template <class C, int EPI, bool DUAL>
+template <class C, int EPI, bool DUAL, bool K0 = false>
 __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
                                               v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
                                               char *q_tile, char *res_tile, const char *ctab_lds,
@@ -652,11 +653,11 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const v4i t = *reinterpret_cast<const v4i *>(ctab_lds + (lch + 4 * g + j) * 16);
-                dm[j].m = t.x, dm[j].s = t.y & 0xff, dm[j].k = t.y >> 8;
+                dm[j].m = t.x, dm[j].s = K0 ? t.y : (t.y & 0xff), dm[j].k = K0 ? 0 : (t.y >> 8);
                 dm[j].add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
                 if constexpr (DUAL) {
                     const v4i u = *reinterpret_cast<const v4i *>(ctab_lds + C::BN * 16 + (lch + 4 * g + j) * 16);
-                    di[j].m = u.x, di[j].s = u.y & 0xff, di[j].k = u.y >> 8;
+                    di[j].m = u.x, di[j].s = K0 ? u.y : (u.y & 0xff), di[j].k = K0 ? 0 : (u.y >> 8);
                     di[j].add = (long long)(((unsigned long long)(unsigned)u.w << 32) | (unsigned)u.z);
                 } else {
                     di[j] = dids;
@@ -670,7 +671,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     // ReLU commutes with the (monotone, 0 -> 0) requantisation: it is folded into q_lo
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        qv[j] = min(max(dyadic_nt(acc[c][q][4 * g + j], dm[j]), p.q_lo), p.q_hi);
+                        qv[j] = med3i(dyadic_nt_k<K0>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
                 } else {
                     int idin[4], o[4];
                     if constexpr (DUAL) {
@@ -683,10 +684,10 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int a = dyadic_nt(acc[c][q][4 * g + j], dm[j]);
-                        const int b = dyadic_nt(idin[j], di[j]);
+                        const int a = dyadic_nt_k<K0>(acc[c][q][4 * g + j], dm[j]);
+                        const int b = DUAL ? dyadic_nt_k<K0>(idin[j], di[j]) : dyadic_nt(idin[j], di[j]);
                         o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
-                        qv[j] = min(dyadic_nt(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
+                        qv[j] = min(dyadic_nt_k<K0>(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
                     }
                     // rows beyond M hold bias-only garbage: they never reach memory and must not raise the flag
                     oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask[q];
@@ -823,7 +824,10 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     }
     if (p.dbg & 4) return;
     if constexpr (FAST)
-        epilogue_fast<C, EPI, DUAL>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
+        if (p.k0)
+            epilogue_fast<C, EPI, DUAL, true>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
+        else
+            epilogue_fast<C, EPI, DUAL, false>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
     else
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
@@ -1061,7 +1065,10 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
     __syncthreads();
     v16i dummy[1][1];
-    epilogue_fast<C, HAWQ_EPI_REQUANT, false>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    if (p.k0)
+        epilogue_fast<C, HAWQ_EPI_REQUANT, false, true>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    else
+        epilogue_fast<C, HAWQ_EPI_REQUANT, false, false>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
     if (prof && blockIdx.x == 8 && t == 0) {
         p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
         p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
@@ -1206,6 +1213,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if ((p.dbg & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
     if (p.dbg & 128) p.dbgbuf = dbg_dev;
     const bool fast = a->fast_tables != 0;
+    p.k0 = (a->fast_tables & 2) ? 1 : 0;
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
         if (a->epilogue == HAWQ_EPI_REQUANT && a->relu && p.q_lo < 0) p.q_lo = 0;  // ReLU folded into the clamp
@@ -1218,6 +1226,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         if (a->out_q) {
             HAWQ_REQUIRE(a->mq >= 0 && e_any(a->eq), "hawq_conv2d: bad (mq, eq)");
             HAWQ_REQUIRE(!fast || e_fast(a->eq), "hawq_conv2d: fast_tables needs eq in [33,62]");
+            HAWQ_REQUIRE(!p.k0 || (a->eq >> 8) == 0, "hawq_conv2d: fast_tables bit 1 (no pre-shifts) but eq carries one");
         } else {
             p.mq = 0, p.eq = 33;
         }

@@ -37,6 +37,11 @@ def _i32(arr, dev):
     return torch.from_numpy(np.ascontiguousarray(arr, np.int32)).to(dev)
 
 
+def _no_preshift(ek) -> bool:
+    """True if no entry of a device table (e | k << 8) carries a pre-shift k."""
+    return bool((np.asarray(ek, dtype=np.int64) >> 8 == 0).all())
+
+
 def _act_range(bits, mode):
     if mode == 'symmetric':
         return -(2 ** (bits - 1)), 2 ** (bits - 1) - 1
@@ -183,7 +188,7 @@ class IntegerEngine:
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
                                rng=_act_range(act.activation_bit, act.quant_mode),
-                               fast=tables_are_fast(mm, ee, c.vbits))
+                               fast=tables_are_fast(mm, ee, c.vbits), k0=_no_preshift(ee))
                     if ent['fast']:
                         ent['ctab'] = _i32(packing.pack_ctab(c.b_host, mm, ee), dev)
                     s_x, bits_x = s_n, ent['out_bits']
@@ -194,13 +199,14 @@ class IntegerEngine:
             s_o = self._scale(ao)
             last = d['convs'][-1]
             mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o, vbits=last['conv'].vbits)
-            last.update(m=_i32(mm, dev), e=_i32(ee, dev))
+            last.update(m=_i32(mm, dev), e=_i32(ee, dev), k0=_no_preshift(ee))
             fast = tables_are_fast(mm, ee, last['conv'].vbits)
             if fast:
                 last['ctab'] = _i32(packing.pack_ctab(last['conv'].b_host, mm, ee), dev)
             if d['resize']:
                 m1, e1 = requant_table(s_a, d['ident'].s_w, s_o, vbits=d['ident'].vbits)
                 d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
+                last['k0'] = last['k0'] and _no_preshift(e1)
                 if tables_are_fast(m1, e1, d['ident'].vbits):
                     d['ctab_id'] = _i32(packing.pack_ctab(d['ident'].b_host, m1, e1), dev)
                 else:
@@ -214,6 +220,7 @@ class IntegerEngine:
             if units:
                 prev_last = units[-1]['convs'][-1]
                 prev_last['fast'] = prev_last['fast'] and tables_are_fast([d['mq']], [d['eq']], U16_VBITS)
+                prev_last['k0'] = prev_last['k0'] and _no_preshift([d['eq']])
             s_prev = s_o
             units.append(d)
         P['units'] = units
@@ -304,14 +311,14 @@ class IntegerEngine:
                 self.subs.append(sub)
                 b0 = b1
             self._ops, self._keep, self._batch, self._graph = _OpList(), [], (N, H, W), None
-            self.n_fast, self.n_conv = self.subs[0].n_fast, self.subs[0].n_conv
+            self.n_fast, self.n_conv, self.n_k0 = self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0
             self.tile_choice = self.subs[0].tile_choice
             return
         self.subs = []
         ops, keep = _OpList(), []
         self._conv_args, self._conv_names = [], []
         self.acc_taps = {}
-        self.n_fast = self.n_conv = 0  # how many conv launches run the fast-contract kernels
+        self.n_fast = self.n_conv = self.n_k0 = 0  # how many conv launches run the fast-contract kernels (/ shift-free)
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
         rdt = torch.uint16 if self.res_bits == 16 else torch.int32
@@ -364,11 +371,14 @@ class IntegerEngine:
                 a.m, a.e = ent['m'].data_ptr(), ent['e'].data_ptr()
                 a.flags = self.flags.data_ptr()
                 a.fast_tables = int(bool(ent.get('fast', False)) and self.res_bits == 16 and self.fast)
+                if a.fast_tables and ent.get('k0', False):
+                    a.fast_tables = 3  # no pre-shift anywhere: the shorter requant
+                self.n_k0 += int(a.fast_tables == 3)
                 if a.fast_tables:
                     a.ctab = ent['ctab'].data_ptr()
                     if ci == len(u['convs']) - 1 and u['resize']:
                         a.ctab_id = u['ctab_id'].data_ptr()
-                self.n_fast += int(a.fast_tables)
+                self.n_fast += int(a.fast_tables != 0)
                 self.n_conv += 1
                 a.tile = int(os.environ.get("HAWQ_TILE_RES" if ci == len(u['convs']) - 1 else "HAWQ_TILE_REQ", "0"))
                 tap_name = f"{u['name']}.quant_convbn{ci + 1}"

@@ -105,7 +105,10 @@ typedef struct hawq_conv_args {
                              Enables the 2-instruction requant path and the LDS-staged coalesced
                              epilogue (8/8 and 4/4 operand widths, 16-bit residuals); needs ctab
                              (and ctab_id with a second branch).  0 = exact general path (any e in
-                             [1,62], any k, ties handled) driven by bias / m / e.                 */
+                             [1,62], any k, ties handled) driven by bias / m / e.
+                             Bit 1 (value 3): additionally every pre-shift k of ctab, ctab_id and
+                             (mq, eq) is 0 - one instruction less per requant (the scalar identity
+                             table (m_id_scalar, e_id_scalar) may still carry one).               */
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);

@@ -131,12 +131,12 @@ def test_conv_identity_weights_asymmetric(lib):
     assert np.array_equal(out.cpu().numpy().reshape(n, h, w, c).transpose(0, 3, 1, 2), x)
 
 
-@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("fast", [0, 1, 3])
 @pytest.mark.parametrize("out_bits", [8, 4])
 @pytest.mark.parametrize("bits", [(8, 8), (4, 4)])
 def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
-    """fast=1: host-proved tie-free tables -> LDS-staged 2-instruction requant kernels;
-    fast=0: exact general kernels, with forced exact .5 ties."""
+    """fast=1: host-proved tie-free tables -> LDS-staged 2-instruction requant kernels; fast=3: additionally no
+    pre-shift in any table (one instruction less); fast=0: exact general kernels, with forced exact .5 ties."""
     from hawq_amd.quant_utils import tables_are_fast
     rng = np.random.default_rng(5)
     n, h, w, cin, cout, k = 2, 12, 12, 128, 128, 3
@@ -145,6 +145,7 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
     m, e = rand_tables(rng, cout, 2e-5 if bits[0] == 8 else 2e-3, 3e-4 if bits[0] == 8 else 2e-2)
     if fast:
         assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
+        assert fast != 3 or (e >> 8 == 0).all()
     else:
         m[0], e[0] = 1 << 30, 33 | (1 << 8)  # ratio 1/4 (e=32 lifted by k=1): produces exact .5 ties
         assert not tables_are_fast(m, e, 20)
@@ -213,7 +214,7 @@ def test_conv3x3_band_kernels(lib, orc, shape):
     assert lib.load().hawq_conv2d(C.byref(a), None) != 0
 
 
-@pytest.mark.parametrize("fast", [0, 1])
+@pytest.mark.parametrize("fast", [0, 1, 3])
 @pytest.mark.parametrize("res_bits", [16, 32])
 @pytest.mark.parametrize("dual", [False, True])
 def test_conv_residual_epilogue(lib, orc, dual, res_bits, fast):
@@ -259,6 +260,8 @@ def test_conv_residual_epilogue(lib, orc, dual, res_bits, fast):
         vb = int(np.abs(acc).max()).bit_length() + 1
         assert tables_are_fast(m2, e2, vb) and tables_are_fast(m1, e1, 22 if dual else 17, allow_shift=not dual)
         assert tables_are_fast(mq, eq, 17)
+        # fast=3: no pre-shift in the conv tables and (mq, eq); the scalar identity table may keep its own
+        assert fast != 3 or ((e2 >> 8 == 0).all() and (not dual or (e1 >> 8 == 0).all()) and int(eq[0]) >> 8 == 0)
     a.fast_tables = fast  # (32-bit residuals run the general kernels either way)
     if fast:
         from hawq_amd.packing import pack_ctab
