@@ -216,7 +216,7 @@ def main():
                 "hbm_frac": round(db / dms / 1e6 / roofline.HBM_PEAK_GBS, 4),
                 "mfma_frac": round(2 * dm / (dms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)}
             if args.per_op:
-                write_per_op(args.per_op, ops, rows, args.batch)
+                write_per_op(args.per_op, ops, rows, out["roofline"]["eager_sum_batch"])
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, x, eng.logits)
         else:

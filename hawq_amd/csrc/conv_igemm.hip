@@ -46,6 +46,7 @@ struct ConvP {
     int32_t *flags;
     const int32_t *ctab, *ctab_id;
     int k0;   // fast path: every pre-shift of ctab / ctab_id / (mq, eq) is 0
+    int ring_bytes;  // LDS bytes of the operand ring actually allocated (fewer stages when the K loop is shorter than the ring)
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     const int tc = wg % tiles_c, tm = wg / tiles_c;  // channel tiles of one pixel tile are adjacent
     const int m0 = tm * C::BM, c0 = tc * C::BN;
     constexpr bool FAST = BITS != 0 && (EPI == HAWQ_EPI_REQUANT || EPI == HAWQ_EPI_RESIDUAL);
-    char *res_tile = smem + C::LDS_BYTES;
+    char *res_tile = smem + p.ring_bytes;
     char *ctab_lds = res_tile + (EPI == HAWQ_EPI_RESIDUAL ? C::BM * C::BN * 2 : 0);  // [BN][16 B] (+ second branch)
     if constexpr (FAST) {
         // the per-channel requant constants of this tile go to LDS asynchronously, off the epilogue's critical path
@@ -1106,7 +1107,7 @@ typedef void (*KernelFn)(const ConvP);
 // single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
 // dual-branch (RESIDUAL + identity conv): {run-time, 88/88, 44/44, 88/44, 44/88}
 struct TileInfo {
-    int BM, BN, lds, ksub, twin, nt;  // twin: tile id to fall back to when KSUB == 2 does not divide the chunk count
+    int BM, BN, lds, ksub, twin, nt, ns;  // twin: tile id to fall back to when KSUB == 2 does not divide the chunk count
     KernelFn single[4][3];
     KernelFn dual[5];
 };
@@ -1114,7 +1115,7 @@ struct TileInfo {
     { conv_kernel<T, E, false, 0, 0>, conv_kernel<T, E, false, 0x88, 0>, conv_kernel<T, E, false, 0x44, 0> }
 #define TILE_ENTRY(T, TWIN)                                                                                          \
     {                                                                                                          \
-        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN, T::NT,                                                             \
+        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN, T::NT, T::NS,                                                          \
             {SINGLE_ROW(T, HAWQ_EPI_RAW), SINGLE_ROW(T, HAWQ_EPI_REQUANT), SINGLE_ROW(T, HAWQ_EPI_RESIDUAL),   \
              SINGLE_ROW(T, HAWQ_EPI_DEQUANT)},                                                                 \
         {                                                                                                      \
@@ -1320,6 +1321,18 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     };
     KernelFn fn;
     int lds = ti.lds;
+    {   // a K loop shorter than the ring needs fewer stages: less LDS = more resident workgroups (the K = 64 expand
+        // convs of stage 1 run a single stage).  Only the all-int8 asynchronous pipeline; the register-staged
+        // and 4-bit paths keep the full ring.
+        const int stages = (a->KH * a->KW * (a->Cin >> 6) + (dual ? (a->Cin2 >> 6) : 0)) / ti.ksub;
+        const bool all88 = a->in_bits == 8 && a->w_bits == 8 && (!dual || (a->in2_bits == 8 && a->w2_bits == 8));
+        const int stage_bytes = ti.lds / ti.ns;
+        static const bool full_ring = getenv("HAWQ_FULL_RING") != nullptr;  // A/B switch for measurements
+        if (!full_ring && all88 && fast && needs_tables && !wide_res && stages >= 1 && stages < ti.ns &&
+            stages * stage_bytes >= ti.BM * ti.BN)  // (the int8 output tile is staged on top of the ring)
+            lds = stages * stage_bytes;
+    }
+    p.ring_bytes = lds;
     if (dual) {
         const int v1 = variant(p.in_bits, p.w_bits), v2 = variant(p.in2_bits, p.w2_bits);
         fn = (v1 == 0 || v2 == 0) ? ti.dual[0] : ti.dual[v1 == v2 ? v1 : (v1 == 1 ? 3 : 4)];

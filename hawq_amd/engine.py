@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from functools import partial
 
 import numpy as np
@@ -445,6 +446,8 @@ class IntegerEngine:
             self._add_acc_tap(ops, keep, a, 'quant_output', N, 1, 1, fc['nout_p'])
         ops.next_name = "quant_output"
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+        self._conv_args.append(a)  # the FC GEMM (M = batch, K = 2048) is tile-tuned like the convs
+        self._conv_names.append("quant_output")
         keep += [qf, pooled, a]
         self._ops, self._keep, self._batch = ops, keep, (N, H, W)
         self._graph = None
@@ -498,7 +501,7 @@ class IntegerEngine:
             for name, a in [(n, k) for n, k in zip(self._conv_names, self._conv_args)]:
                 if os.environ.get("HAWQ_TILE_RES") or os.environ.get("HAWQ_TILE_REQ"):
                     break
-                best, best_t = None, 0
+                best, best_t, log = None, 0, []
                 for tile in range(1, n_tiles + 1):
                     a.tile = tile
                     try:
@@ -510,8 +513,11 @@ class IntegerEngine:
                         _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
                     except RuntimeError:
                         continue
+                    log.append(f"{tile}:{ms.value / reps * 1e3:.1f}")
                     if best is None or ms.value < best:
                         best, best_t = ms.value, tile
+                if os.environ.get("HAWQ_AUTOTUNE_LOG"):
+                    print(f"[autotune N={a.N}] {name}: best {best_t}  us per tile: {' '.join(log)}", file=sys.stderr)
                 a.tile = best_t
                 self.tile_choice[name] = best_t
         _lib.call("hawq_event_destroy", e0)
