@@ -871,7 +871,11 @@ struct BandCfg {
     static_assert(BM * BN * 2 <= LDS_BYTES, "epilogue staging aliases the rings");
 };
 
-template <class C>
+// NIB: both operands hawq4 nibble-packed (Cin % 128 == 0).  A 64-byte slice is then 128 channels, the packed bytes
+// travel through LDS untouched and every 16-byte fragment read (32 channels) feeds TWO MFMA K-steps after
+// unpacking in registers (activations zero-extended, weights as value*16, accumulators shifted back by 4 - exact);
+// both operands pair the same channels with the same K-step, so the channel order inside a slice is irrelevant.
+template <class C, bool NIB = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool prof = (p.dbg & 128) && p.dbgbuf;
@@ -894,7 +898,8 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
 
     const int Wo = p.Wo, Wb = Wo + 2;
     const int G0 = m0 / Wo - 1;                 // global row held by band row 0
-    const int cchunks = p.Cin >> 6;
+    const int rowb = NIB ? p.Cin >> 1 : p.Cin;  // bytes per pixel / per filter tap of one output channel
+    const int cchunks = rowb >> 6;
     const int nsteps = 3 * cchunks;             // step s = cc * 3 + kh
 
     // ------------------------------------------------------------------ LDS-DMA side (issuing waves)
@@ -909,12 +914,12 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
             const int br = bpx / Wb, bc = bpx - br * Wb;
             const int G = G0 + br, x = bc - 1;
             const bool v = (unsigned)G < (unsigned)rows_total && (unsigned)x < (unsigned)Wo && bpx < C::BAND_PX - 4;
-            bsrc[i] = v ? (const char *)p.in + ((size_t)G * Wo + x) * p.Cin + ((j & 3) << 4) : nullptr;
+            bsrc[i] = v ? (const char *)p.in + ((size_t)G * Wo + x) * rowb + ((j & 3) << 4) : nullptr;
         }
 #pragma unroll
         for (int r = 0; r < C::RPI; ++r) {
             const int row = (r * C::ND + dw) * 16 + (lane >> 2);
-            wsrc[r] = (const char *)p.wgt + (size_t)(c0 + row) * ((size_t)9 * p.Cin) + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+            wsrc[r] = (const char *)p.wgt + (size_t)(c0 + row) * ((size_t)9 * rowb) + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
         }
     }
     auto issue_band = [&](int cc) {
@@ -929,12 +934,12 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     };
     auto issue_w = [&](int s, int cc, int kh) {  // the 3 taps of filter row kh, channel slice cc -> ring stage s % 3
         char *dst = wring + (s % 3) * C::WSTAGE + dw * 1024;
-        const size_t off = (size_t)(kh * 3) * p.Cin + (cc << 6);
+        const size_t off = (size_t)(kh * 3) * rowb + (cc << 6);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int r = 0; r < C::RPI; ++r)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[r] + off + (size_t)kw * p.Cin),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[r] + off + (size_t)kw * rowb),
                                                  (__attribute__((address_space(3))) void *)(dst + kw * C::WTAP + r * (C::ND * 1024)), 16, 0, 0);
     };
     auto issue_step = [&](int s, int cc, int kh) {  // after the barrier of step s: ring stage (s+2)%3 and band stage (cc+1)&1 are free
@@ -1023,9 +1028,22 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     {                                                                                                             \
         _Pragma("unroll") for (int c = 0; c < C::CT; ++c) pin(wf[(B) & 1][c]);                                    \
         _Pragma("unroll") for (int q = 0; q < C::PT; ++q) pin(af[(B) & 1][q]);                                    \
-        _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                         \
-            _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                                     \
-                acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[(B) & 1][c], af[(B) & 1][q], acc[c][q], 0, 0, 0); \
+        if constexpr (NIB) {                                                                                      \
+            _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                    \
+                v4i w8[C::CT], a8[C::PT];                                                                         \
+                _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                 \
+                    w8[c] = unpack16<true>((unsigned)wf[(B) & 1][c][2 * hf], (unsigned)wf[(B) & 1][c][2 * hf + 1]); \
+                _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                                 \
+                    a8[q] = unpack16<false>((unsigned)af[(B) & 1][q][2 * hf], (unsigned)af[(B) & 1][q][2 * hf + 1]); \
+                _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                 \
+                    _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                             \
+                        acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w8[c], a8[q], acc[c][q], 0, 0, 0);      \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                     \
+                _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                                 \
+                    acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[(B) & 1][c], af[(B) & 1][q], acc[c][q], 0, 0, 0); \
+        }                                                                                                         \
     }
 #define BAND_BATCH(B)                                                                                             \
     {                                                                                                             \
@@ -1064,6 +1082,14 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         if (C::NPROD > 0) __builtin_amdgcn_s_setprio(0);
     }
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
+    if constexpr (NIB) {  // weights were unpacked as value*16
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+            for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[c][q][r] >>= 4;
+    }
     __syncthreads();
     v16i dummy[1][1];
     if (p.k0)
@@ -1271,25 +1297,28 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
     if (tile >= NUM_TILES && tile < NUM_TILES + NUM_BAND_TILES) {
         // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 REQUANT layers only
-        struct BandInfo { KernelFn fn; int bm, bn, band_px, bstages, lds, nt; };
-#define BAND_ENTRY(B) {conv3x3_band_kernel<B>, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
+        struct BandInfo { KernelFn fn, fn4; int bm, bn, band_px, bstages, lds, nt; };
+#define BAND_ENTRY(B) {conv3x3_band_kernel<B, false>, conv3x3_band_kernel<B, true>, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
         static const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2)};
         const BandInfo &bi = kBand[tile - NUM_TILES];
         const int bn = bi.bn;
         const int wo = p.Wo, band_rows = (bi.bm + wo - 1) / wo + 1 + 2;
+        const bool nib = a->in_bits == 4 && a->w_bits == 4;
         const bool ok = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && !dual && fast &&
-                        a->epilogue == HAWQ_EPI_REQUANT && a->in_bits == 8 && a->w_bits == 8 && p.Cout % bn == 0 &&
-                        band_rows * (wo + 2) <= bi.band_px - 4 && a->out_q && (bi.bstages > 1 || a->Cin == 64);
+                        a->epilogue == HAWQ_EPI_REQUANT && ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) &&
+                        p.Cout % bn == 0 && band_rows * (wo + 2) <= bi.band_px - 4 && a->out_q &&
+                        (bi.bstages > 1 || (a->Cin >> (nib ? 7 : 6)) == 1);
         HAWQ_REQUIRE(ok, "hawq_conv2d: tile %d (3x3 band kernel) does not apply to this layer", a->tile);
         static const bool band_attrs = [] {
             bool good = true;
             for (const BandInfo &b : kBand)
-                good &= hipFuncSetAttribute((const void *)b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
+                good &= hipFuncSetAttribute((const void *)b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess &&
+                        hipFuncSetAttribute((const void *)b.fn4, hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
             return good;
         }();
         HAWQ_REQUIRE(band_attrs, "hawq_conv2d: hipFuncSetAttribute failed for the band kernels");
         const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bn);
-        hipLaunchKernelGGL(bi.fn, dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(nib ? bi.fn4 : bi.fn, dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
         HAWQ_CHECK_HIP(hipGetLastError());
         if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
             long long hbuf[4];

@@ -172,16 +172,18 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
 
 @pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (9, 7, 7, 128, 128),
                                    (1, 14, 20, 64, 192), (2, 9, 30, 192, 128), (7, 7, 7, 512, 128), (1, 3, 5, 64, 64)])
-def test_conv3x3_band_kernels(lib, orc, shape):
+@pytest.mark.parametrize("bits", [8, 4])
+def test_conv3x3_band_kernels(lib, orc, shape, bits):
     """The LDS-band 3x3 kernels (the last tile ids) vs the oracle: all ResNet50 spatial sizes, several images per
-    workgroup, ragged last tile, rectangular maps; both ReLU settings; int8 and hawq4 outputs."""
+    workgroup, ragged last tile, rectangular maps; both ReLU settings; int8 and hawq4 outputs; int8 and hawq4
+    (W4A4, Cin % 128 == 0) operands."""
     from hawq_amd.packing import pack_ctab
     from hawq_amd.quant_utils import tables_are_fast
     n, h, w, cin, cout = shape
     rng = np.random.default_rng(h * 1000 + w + cin)
-    x, wt, b = make_conv(rng, n, h, w, cin, cout, 3, 8, 8)
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 3, bits, bits)
     acc = orc.conv2d(x, wt, b, 1, 1)
-    m, e = rand_tables(rng, cout, 2e-5, 3e-4)
+    m, e = rand_tables(rng, cout, 2e-5 if bits == 8 else 2e-3, 3e-4 if bits == 8 else 2e-2)
     assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
     ntiles, nband = lib.load().hawq_conv2d_num_tiles(), lib.load().hawq_conv2d_num_band_tiles()
     # (pixels per workgroup, channel tile, band pixels per LDS stage, needs Cin == 64) of the band tiles, in id order
@@ -189,9 +191,11 @@ def test_conv3x3_band_kernels(lib, orc, shape):
     assert nband == len(geom)
     ran = 0
     for tile, (bm, bn, band_px, cin64) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
-        applies = cout % bn == 0 and ((bm + w - 1) // w + 3) * (w + 2) <= band_px - 4 and (cin == 64 or not cin64)
+        chunks = cin // 64 if bits == 8 else cin // 128
+        applies = (cout % bn == 0 and ((bm + w - 1) // w + 3) * (w + 2) <= band_px - 4 and (chunks == 1 or not cin64)
+                   and (bits == 8 or cin % 128 == 0))
         if not applies:
-            a, keep = conv_args(lib, x, wt, b, 1, 1, 8, 8, tile=tile)
+            a, keep = conv_args(lib, x, wt, b, 1, 1, bits, bits, tile=tile)
             keep.update(ctab=dev(pack_ctab(b, m, e)), m=dev(m), e=dev(e))
             out = torch.zeros(acc.size, dtype=torch.uint8, device='cuda')
             a.epilogue, a.relu, a.m, a.e, a.ctab, a.fast_tables = lib.EPI_REQUANT, 1, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), 1
@@ -199,7 +203,7 @@ def test_conv3x3_band_kernels(lib, orc, shape):
             assert lib.load().hawq_conv2d(C.byref(a), None) != 0   # refused, not mis-computed
             continue
         for relu, out_bits, (lo, hi) in ((1, 8, (-128, 127)), (0, 8, (-128, 127)), (1, 4, (0, 15))):
-            a, keep = conv_args(lib, x, wt, b, 1, 1, 8, 8, tile=tile)
+            a, keep = conv_args(lib, x, wt, b, 1, 1, bits, bits, tile=tile)
             keep.update(ctab=dev(pack_ctab(b, m, e)), m=dev(m), e=dev(e))
             out = torch.zeros(acc.size * out_bits // 8, dtype=torch.uint8, device='cuda')
             a.epilogue, a.relu, a.m, a.e, a.ctab, a.fast_tables = lib.EPI_REQUANT, relu, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), 1
@@ -208,9 +212,9 @@ def test_conv3x3_band_kernels(lib, orc, shape):
             ref = odyadic(orc, np.maximum(acc, 0) if relu else acc, m, e, (lo, hi))
             assert np.array_equal(unpack_q(out, (n, h, w, cout), out_bits), ref), (tile, relu, out_bits)
             ran += 1
-    assert ran >= 3
+    assert ran >= 3 or (bits == 4 and cin % 128)
     # a layer the band kernels cannot take is refused, not mis-computed
-    a, keep = conv_args(lib, x, wt, b, 2, 1, 8, 8, tile=ntiles)
+    a, keep = conv_args(lib, x, wt, b, 2, 1, bits, bits, tile=ntiles)
     assert lib.load().hawq_conv2d(C.byref(a), None) != 0
 
 
