@@ -77,6 +77,23 @@ __device__ __forceinline__ int32_t dyadic_nt_k(int32_t v, const DyNt &c) {
     const long long t = (long long)(K0 ? v : (v << c.k)) * (long long)c.m + c.add;
     return (int)(t >> 32) >> c.s;
 }
+// TIE-aware form for tables whose tie-freedom the host could NOT prove (a few channels with many trailing zeros in
+// m and a small e): half-up first, then the exact-tie correction of round-half-even.  x*m = (2j+1)*2^(e-1) makes
+// t = x*m + 2^(e-1) a multiple of 2^e and half-up returns j+1; RNE wants the even one of {j, j+1}, i.e. one less
+// when the half-up result is odd (holds for negative values too: arithmetic shifts floor).
+__device__ __forceinline__ int32_t dyadic_tie(int32_t v, const DyNt &c) {
+    const long long t = (long long)(v << c.k) * (long long)c.m + c.add;
+    const int hi = (int)(t >> 32);
+    const int q = hi >> c.s;
+    const bool tie = (unsigned)t == 0u && (hi & ((1 << c.s) - 1)) == 0;
+    return q - (tie ? (q & 1) : 0);
+}
+// MODE 0: tie-free table with per-entry pre-shift, 1: tie-free and k == 0, 2: ties possible (exact RNE)
+template <int MODE>
+__device__ __forceinline__ int32_t dyadic_mode(int32_t v, const DyNt &c) {
+    if (MODE == 2) return dyadic_tie(v, c);
+    return dyadic_nt_k<MODE == 1>(v, c);
+}
 // clamp(v, lo, hi) for lo <= hi in one instruction
 __device__ __forceinline__ int32_t med3i(int32_t v, int32_t lo, int32_t hi) {
     int32_t r;

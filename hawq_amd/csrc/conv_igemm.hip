@@ -45,7 +45,7 @@ struct ConvP {
     int ldo, n_valid;
     int32_t *flags;
     const int32_t *ctab, *ctab_id;
-    int k0;   // fast path: every pre-shift of ctab / ctab_id / (mq, eq) is 0
+    int k0;   // fast path requant mode (dyadic_mode): 0 tie-free, 1 tie-free + every pre-shift 0, 2 exact tie handling
     int ring_bytes;  // LDS bytes of the operand ring actually allocated (fewer stages when the K loop is shorter than the ring)
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
@@ -609,7 +609,8 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
     }
 }
 
-template <class C, int EPI, bool DUAL, bool K0 = false>
+// MODE: see dyadic_mode (0 = tie-free tables, 1 = tie-free and shift-free, 2 = exact tie handling for every table)
+template <class C, int EPI, bool DUAL, int MODE = 0>
 __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
                                               v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
                                               char *q_tile, char *res_tile, const char *ctab_lds,
@@ -617,6 +618,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     // active == false: a wave that owns no accumulators (band-kernel producer); it only helps with the stores
     using S = Stage<C>;
     constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
+    constexpr bool K0 = MODE == 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_m = wave % C::WM, wave_c = (wave / C::WM) % C::WN;
     const int l31 = lane & 31, h = lane >> 5;
@@ -672,7 +674,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     // ReLU commutes with the (monotone, 0 -> 0) requantisation: it is folded into q_lo
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        qv[j] = med3i(dyadic_nt_k<K0>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
+                        qv[j] = med3i(dyadic_mode<MODE>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
                 } else {
                     int idin[4], o[4];
                     if constexpr (DUAL) {
@@ -685,10 +687,10 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int a = dyadic_nt_k<K0>(acc[c][q][4 * g + j], dm[j]);
-                        const int b = DUAL ? dyadic_nt_k<K0>(idin[j], di[j]) : dyadic_nt(idin[j], di[j]);
+                        const int a = dyadic_mode<MODE>(acc[c][q][4 * g + j], dm[j]);
+                        const int b = DUAL ? dyadic_mode<MODE>(idin[j], di[j]) : dyadic_mode<MODE == 2 ? 2 : 0>(idin[j], di[j]);
                         o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
-                        qv[j] = min(dyadic_nt_k<K0>(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
+                        qv[j] = min(dyadic_mode<MODE>(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
                     }
                     // rows beyond M hold bias-only garbage: they never reach memory and must not raise the flag
                     oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask[q];
@@ -825,10 +827,12 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     }
     if (p.dbg & 4) return;
     if constexpr (FAST)
-        if (p.k0)
-            epilogue_fast<C, EPI, DUAL, true>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
+        if (p.k0 == 1)
+            epilogue_fast<C, EPI, DUAL, 1>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
+        else if (p.k0 == 2)
+            epilogue_fast<C, EPI, DUAL, 2>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
         else
-            epilogue_fast<C, EPI, DUAL, false>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
+            epilogue_fast<C, EPI, DUAL, 0>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
     else
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
@@ -1092,10 +1096,12 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     }
     __syncthreads();
     v16i dummy[1][1];
-    if (p.k0)
-        epilogue_fast<C, HAWQ_EPI_REQUANT, false, true>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    if (p.k0 == 1)
+        epilogue_fast<C, HAWQ_EPI_REQUANT, false, 1>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    else if (p.k0 == 2)
+        epilogue_fast<C, HAWQ_EPI_REQUANT, false, 2>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
     else
-        epilogue_fast<C, HAWQ_EPI_REQUANT, false, false>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+        epilogue_fast<C, HAWQ_EPI_REQUANT, false, 0>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
     if (prof && blockIdx.x == 8 && t == 0) {
         p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
         p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
@@ -1240,7 +1246,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if ((p.dbg & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
     if (p.dbg & 128) p.dbgbuf = dbg_dev;
     const bool fast = a->fast_tables != 0;
-    p.k0 = (a->fast_tables & 2) ? 1 : 0;
+    p.k0 = (a->fast_tables & 4) ? 2 : ((a->fast_tables & 2) ? 1 : 0);
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
         if (a->epilogue == HAWQ_EPI_REQUANT && a->relu && p.q_lo < 0) p.q_lo = 0;  // ReLU folded into the clamp
@@ -1253,7 +1259,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         if (a->out_q) {
             HAWQ_REQUIRE(a->mq >= 0 && e_any(a->eq), "hawq_conv2d: bad (mq, eq)");
             HAWQ_REQUIRE(!fast || e_fast(a->eq), "hawq_conv2d: fast_tables needs eq in [33,62]");
-            HAWQ_REQUIRE(!p.k0 || (a->eq >> 8) == 0, "hawq_conv2d: fast_tables bit 1 (no pre-shifts) but eq carries one");
+            HAWQ_REQUIRE(p.k0 != 1 || (a->eq >> 8) == 0, "hawq_conv2d: fast_tables bit 1 (no pre-shifts) but eq carries one");
         } else {
             p.mq = 0, p.eq = 33;
         }

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import _lib, packing
-from .quant_utils import requant_table, tables_are_fast
+from .quant_utils import requant_table, tables_are_fast, tables_fit_fast
 
 
 RES_VBITS = 20  # residual / pooled values are 16-bit-ish (uint16 storage saturates at 65535)
@@ -189,7 +189,8 @@ class IntegerEngine:
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
                                rng=_act_range(act.activation_bit, act.quant_mode),
-                               fast=tables_are_fast(mm, ee, c.vbits), k0=_no_preshift(ee))
+                               fast=tables_fit_fast(mm, ee, c.vbits), tie=not tables_are_fast(mm, ee, c.vbits),
+                               k0=_no_preshift(ee))
                     if ent['fast']:
                         ent['ctab'] = _i32(packing.pack_ctab(c.b_host, mm, ee), dev)
                     s_x, bits_x = s_n, ent['out_bits']
@@ -201,26 +202,30 @@ class IntegerEngine:
             last = d['convs'][-1]
             mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o, vbits=last['conv'].vbits)
             last.update(m=_i32(mm, dev), e=_i32(ee, dev), k0=_no_preshift(ee))
-            fast = tables_are_fast(mm, ee, last['conv'].vbits)
+            fast = tables_fit_fast(mm, ee, last['conv'].vbits)
+            tie = not tables_are_fast(mm, ee, last['conv'].vbits)
             if fast:
                 last['ctab'] = _i32(packing.pack_ctab(last['conv'].b_host, mm, ee), dev)
             if d['resize']:
                 m1, e1 = requant_table(s_a, d['ident'].s_w, s_o, vbits=d['ident'].vbits)
                 d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
                 last['k0'] = last['k0'] and _no_preshift(e1)
-                if tables_are_fast(m1, e1, d['ident'].vbits):
+                if tables_fit_fast(m1, e1, d['ident'].vbits):
                     d['ctab_id'] = _i32(packing.pack_ctab(d['ident'].b_host, m1, e1), dev)
+                    tie = tie or not tables_are_fast(m1, e1, d['ident'].vbits)
                 else:
                     fast = False
             else:
                 m1, e1 = requant_table(s_prev, one, s_o, vbits=RES_VBITS)
                 d['m_id_s'], d['e_id_s'] = int(m1[0]), int(e1[0])
-                fast = fast and tables_are_fast(m1, e1, U16_VBITS, allow_shift=True)
-            last['fast'] = fast
-            # the next unit's block-input QuantAct is fused into this launch: its table must be fast too
+                fast = fast and tables_fit_fast(m1, e1, U16_VBITS, allow_shift=True)
+                tie = tie or not tables_are_fast(m1, e1, U16_VBITS, allow_shift=True)
+            last['fast'], last['tie'] = fast, tie
+            # the next unit's block-input QuantAct is fused into this launch: its table must fit the fast path too
             if units:
                 prev_last = units[-1]['convs'][-1]
-                prev_last['fast'] = prev_last['fast'] and tables_are_fast([d['mq']], [d['eq']], U16_VBITS)
+                prev_last['fast'] = prev_last['fast'] and tables_fit_fast([d['mq']], [d['eq']], U16_VBITS)
+                prev_last['tie'] = prev_last['tie'] or not tables_are_fast([d['mq']], [d['eq']], U16_VBITS)
                 prev_last['k0'] = prev_last['k0'] and _no_preshift([d['eq']])
             s_prev = s_o
             units.append(d)
@@ -312,14 +317,15 @@ class IntegerEngine:
                 self.subs.append(sub)
                 b0 = b1
             self._ops, self._keep, self._batch, self._graph = _OpList(), [], (N, H, W), None
-            self.n_fast, self.n_conv, self.n_k0 = self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0
+            self.n_fast, self.n_conv, self.n_k0, self.n_tie = (self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0,
+                                                              self.subs[0].n_tie)
             self.tile_choice = self.subs[0].tile_choice
             return
         self.subs = []
         ops, keep = _OpList(), []
         self._conv_args, self._conv_names = [], []
         self.acc_taps = {}
-        self.n_fast = self.n_conv = self.n_k0 = 0  # how many conv launches run the fast-contract kernels (/ shift-free)
+        self.n_fast = self.n_conv = self.n_k0 = self.n_tie = 0  # how many conv launches run the fast-contract kernels (/ shift-free)
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
         rdt = torch.uint16 if self.res_bits == 16 else torch.int32
@@ -372,8 +378,11 @@ class IntegerEngine:
                 a.m, a.e = ent['m'].data_ptr(), ent['e'].data_ptr()
                 a.flags = self.flags.data_ptr()
                 a.fast_tables = int(bool(ent.get('fast', False)) and self.res_bits == 16 and self.fast)
-                if a.fast_tables and ent.get('k0', False):
+                if a.fast_tables and ent.get('tie', False):
+                    a.fast_tables = 5  # some table is not provably tie-free: exact tie handling in the epilogue
+                elif a.fast_tables and ent.get('k0', False):
                     a.fast_tables = 3  # no pre-shift anywhere: the shorter requant
+                self.n_tie += int(a.fast_tables == 5)
                 self.n_k0 += int(a.fast_tables == 3)
                 if a.fast_tables:
                     a.ctab = ent['ctab'].data_ptr()

@@ -95,6 +95,18 @@ def requant_table(pre_act_scaling_factor, pre_weight_scaling_factor, z_scaling_f
     return m.astype(np.int32), (e | (k << 8)).astype(np.int32)
 
 
+def tables_fit_fast(m, ek, vbits, allow_shift=True) -> bool:
+    """The structural half of the fast contract: e in [33, 62] and |v << k| < 2^31 for |v| < 2^vbits.  Tables that
+    fit but are not provably tie-free (``tables_are_fast``) run the fast kernels in their exact-tie mode
+    (``fast_tables`` bit 2)."""
+    ek = np.asarray(ek, np.int64).reshape(-1)
+    e, k = ek & 0xff, ek >> 8
+    vb = np.broadcast_to(np.asarray(vbits, np.int64), ek.shape)
+    if ((e < 33) | (e > 62)).any():
+        return False
+    return not (((k != 0).any() and not allow_shift) or (vb + k > 31).any())
+
+
 def tables_are_fast(m, ek, vbits, allow_shift=True) -> bool:
     """True if a (m, ek) table satisfies the conv kernels' fast contract for inputs |v| < 2^vbits:
     e in [33, 62], vbits + k <= 31, and no exact rounding tie is possible.  A tie needs

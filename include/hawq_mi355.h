@@ -108,7 +108,10 @@ typedef struct hawq_conv_args {
                              [1,62], any k, ties handled) driven by bias / m / e.
                              Bit 1 (value 3): additionally every pre-shift k of ctab, ctab_id and
                              (mq, eq) is 0 - one instruction less per requant (the scalar identity
-                             table (m_id_scalar, e_id_scalar) may still carry one).               */
+                             table (m_id_scalar, e_id_scalar) may still carry one).
+                             Bit 2 (value 5): the tie-freedom proof FAILED for some entry; the kernel
+                             then applies the exact round-half-even tie correction to every requant
+                             of the call (e in [33,62] and |value << k| < 2^31 still required).     */
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);

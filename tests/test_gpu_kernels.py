@@ -131,23 +131,30 @@ def test_conv_identity_weights_asymmetric(lib):
     assert np.array_equal(out.cpu().numpy().reshape(n, h, w, c).transpose(0, 3, 1, 2), x)
 
 
-@pytest.mark.parametrize("fast", [0, 1, 3])
+@pytest.mark.parametrize("fast", [0, 1, 3, 5])
 @pytest.mark.parametrize("out_bits", [8, 4])
 @pytest.mark.parametrize("bits", [(8, 8), (4, 4)])
 def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
     """fast=1: host-proved tie-free tables -> LDS-staged 2-instruction requant kernels; fast=3: additionally no
-    pre-shift in any table (one instruction less); fast=0: exact general kernels, with forced exact .5 ties."""
+    pre-shift in any table (one instruction less); fast=5: fast kernels in exact-tie mode, with forced exact .5
+    ties; fast=0: exact general kernels, with forced exact .5 ties."""
     from hawq_amd.quant_utils import tables_are_fast
     rng = np.random.default_rng(5)
     n, h, w, cin, cout, k = 2, 12, 12, 128, 128, 3
     x, wt, b = make_conv(rng, n, h, w, cin, cout, k, *bits)
     acc = orc.conv2d(x, wt, b, 1, 1)
+    for c in (0, 1):  # channels 0 / 1 get the tie-prone tables below: centre their accumulators on zero
+        b[c] += 2 - int(np.median(acc[:, c]))
+    acc = orc.conv2d(x, wt, b, 1, 1)
     m, e = rand_tables(rng, cout, 2e-5 if bits[0] == 8 else 2e-3, 3e-4 if bits[0] == 8 else 2e-2)
-    if fast:
+    if fast in (1, 3):
         assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
         assert fast != 3 or (e >> 8 == 0).all()
     else:
         m[0], e[0] = 1 << 30, 33 | (1 << 8)  # ratio 1/4 (e=32 lifted by k=1): produces exact .5 ties
+        m[1], e[1] = 3 << 29, 34             # ratio 3/16: ties whenever acc = 8 mod 16
+        pos = acc[:, 0][acc[:, 0] > 0].astype(np.int64)
+        assert (pos % 4 == 2).any()  # the data does contain exact .5 ties (on both parities of the quotient)
         assert not tables_are_fast(m, e, 20)
     lo, hi = (-128, 127) if out_bits == 8 else (0, 15)
     ref = odyadic(orc, np.maximum(acc, 0), m, e, (lo, hi))
@@ -218,7 +225,7 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
     assert lib.load().hawq_conv2d(C.byref(a), None) != 0
 
 
-@pytest.mark.parametrize("fast", [0, 1, 3])
+@pytest.mark.parametrize("fast", [0, 1, 3, 5])
 @pytest.mark.parametrize("res_bits", [16, 32])
 @pytest.mark.parametrize("dual", [False, True])
 def test_conv_residual_epilogue(lib, orc, dual, res_bits, fast):
