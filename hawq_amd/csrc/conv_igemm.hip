@@ -609,7 +609,9 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
     }
 }
 
-// MODE: see dyadic_mode (0 = tie-free tables, 1 = tie-free and shift-free, 2 = exact tie handling for every table)
+// MODE: see dyadic_mode (0 = tie-free tables, 2 = exact tie handling for every table; 1 = tie-free and shift-free is
+// implemented but not instantiated: as a run-time variant it cost registers (spills in the 64x64 dual kernels) for
+// a gain inside the measurement noise)
 template <class C, int EPI, bool DUAL, int MODE = 0>
 __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
                                               v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
@@ -762,7 +764,10 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     }
 }
 
-template <class C, int EPI, bool DUAL, int BITS, int BITS2>
+// TIE: the launch's tables are not provably tie-free -> every requant of the fast epilogue applies the exact
+// round-half-even correction (dyadic_tie).  A separate instantiation, not a run-time branch: the correction costs
+// registers, and register allocation is per kernel (as a branch it pushed the 64x64 dual kernels into 44 spills).
+template <class C, int EPI, bool DUAL, int BITS, int BITS2, bool TIE = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
@@ -827,12 +832,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     }
     if (p.dbg & 4) return;
     if constexpr (FAST)
-        if (p.k0 == 1)
-            epilogue_fast<C, EPI, DUAL, 1>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
-        else if (p.k0 == 2)
-            epilogue_fast<C, EPI, DUAL, 2>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
-        else
-            epilogue_fast<C, EPI, DUAL, 0>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
+        epilogue_fast<C, EPI, DUAL, TIE ? 2 : 0>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
     else
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
 }
@@ -879,7 +879,7 @@ struct BandCfg {
 // travel through LDS untouched and every 16-byte fragment read (32 channels) feeds TWO MFMA K-steps after
 // unpacking in registers (activations zero-extended, weights as value*16, accumulators shifted back by 4 - exact);
 // both operands pair the same channels with the same K-step, so the channel order inside a slice is irrelevant.
-template <class C, bool NIB = false>
+template <class C, bool NIB = false, bool TIE = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool prof = (p.dbg & 128) && p.dbgbuf;
@@ -1096,12 +1096,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     }
     __syncthreads();
     v16i dummy[1][1];
-    if (p.k0 == 1)
-        epilogue_fast<C, HAWQ_EPI_REQUANT, false, 1>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
-    else if (p.k0 == 2)
-        epilogue_fast<C, HAWQ_EPI_REQUANT, false, 2>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
-    else
-        epilogue_fast<C, HAWQ_EPI_REQUANT, false, 0>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    epilogue_fast<C, HAWQ_EPI_REQUANT, false, TIE ? 2 : 0>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
     if (prof && blockIdx.x == 8 && t == 0) {
         p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
         p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
@@ -1142,6 +1137,8 @@ struct TileInfo {
     int BM, BN, lds, ksub, twin, nt, ns;  // twin: tile id to fall back to when KSUB == 2 does not divide the chunk count
     KernelFn single[4][3];
     KernelFn dual[5];
+    KernelFn tie_single[2][2];  // exact-tie instantiations: {REQUANT, RESIDUAL} x {8/8, 4/4}
+    KernelFn tie_dual[2];       // {88/88, 44/44}
 };
 #define SINGLE_ROW(T, E) \
     { conv_kernel<T, E, false, 0, 0>, conv_kernel<T, E, false, 0x88, 0>, conv_kernel<T, E, false, 0x44, 0> }
@@ -1155,7 +1152,10 @@ struct TileInfo {
                 conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x44, 0x44>,                                           \
                 conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x88, 0x44>,                                           \
                 conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x44, 0x88>                                            \
-        }                                                                                                      \
+        },                                                                                                     \
+        {{conv_kernel<T, HAWQ_EPI_REQUANT, false, 0x88, 0, true>, conv_kernel<T, HAWQ_EPI_REQUANT, false, 0x44, 0, true>},   \
+         {conv_kernel<T, HAWQ_EPI_RESIDUAL, false, 0x88, 0, true>, conv_kernel<T, HAWQ_EPI_RESIDUAL, false, 0x44, 0, true>}}, \
+        {conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x88, 0x88, true>, conv_kernel<T, HAWQ_EPI_RESIDUAL, true, 0x44, 0x44, true>} \
     }
 const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0, 0), TILE_ENTRY(T1, 1), TILE_ENTRY(T2, 2), TILE_ENTRY(T3, 3),
                                     TILE_ENTRY(T4, 0), TILE_ENTRY(T5, 2), TILE_ENTRY(T6, 3),
@@ -1168,6 +1168,9 @@ bool raise_lds_limits() {
     for (const TileInfo &ti : kTiles) {
         const int lds = ti.lds + ti.BM * ti.BN * 2 + ti.BN * 32;
         if (lds <= 64 * 1024) continue;
+        for (int v = 0; v < 2; ++v)
+            ok &= hipFuncSetAttribute((const void *)ti.tie_single[1][v], hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+                  hipFuncSetAttribute((const void *)ti.tie_dual[v], hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         for (int v = 1; v < 3; ++v)
             ok &= hipFuncSetAttribute((const void *)ti.single[2][v], hipFuncAttributeMaxDynamicSharedMemorySize, lds) ==
                   hipSuccess;
@@ -1303,8 +1306,8 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
     if (tile >= NUM_TILES && tile < NUM_TILES + NUM_BAND_TILES) {
         // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 REQUANT layers only
-        struct BandInfo { KernelFn fn, fn4; int bm, bn, band_px, bstages, lds, nt; };
-#define BAND_ENTRY(B) {conv3x3_band_kernel<B, false>, conv3x3_band_kernel<B, true>, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
+        struct BandInfo { KernelFn fn[2][2]; int bm, bn, band_px, bstages, lds, nt; };  // fn[hawq4][exact-tie]
+#define BAND_ENTRY(B) {{{conv3x3_band_kernel<B, false, false>, conv3x3_band_kernel<B, false, true>}, {conv3x3_band_kernel<B, true, false>, conv3x3_band_kernel<B, true, true>}}, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
         static const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2)};
         const BandInfo &bi = kBand[tile - NUM_TILES];
         const int bn = bi.bn;
@@ -1318,13 +1321,13 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         static const bool band_attrs = [] {
             bool good = true;
             for (const BandInfo &b : kBand)
-                good &= hipFuncSetAttribute((const void *)b.fn, hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess &&
-                        hipFuncSetAttribute((const void *)b.fn4, hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
+                for (int i = 0; i < 4; ++i)
+                    good &= hipFuncSetAttribute((const void *)b.fn[i >> 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
             return good;
         }();
         HAWQ_REQUIRE(band_attrs, "hawq_conv2d: hipFuncSetAttribute failed for the band kernels");
         const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bn);
-        hipLaunchKernelGGL(nib ? bi.fn4 : bi.fn, dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(bi.fn[nib ? 1 : 0][p.k0 == 2 ? 1 : 0], dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
         HAWQ_CHECK_HIP(hipGetLastError());
         if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
             long long hbuf[4];
@@ -1371,10 +1374,15 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (dual) {
         const int v1 = variant(p.in_bits, p.w_bits), v2 = variant(p.in2_bits, p.w2_bits);
         fn = (v1 == 0 || v2 == 0) ? ti.dual[0] : ti.dual[v1 == v2 ? v1 : (v1 == 1 ? 3 : 4)];
+        if (p.k0 == 2 && v1 != 0 && v2 != 0) {
+            HAWQ_REQUIRE(v1 == v2, "hawq_conv2d: exact-tie mode (fast_tables bit 2) needs equal operand widths in both branches");
+            fn = ti.tie_dual[v1 - 1];
+        }
         if (v1 != 0 && v2 != 0) lds += ti.BM * ti.BN * 2 + ti.BN * 32;
     } else {
         const int v = variant(p.in_bits, p.w_bits);
         fn = ti.single[slot][v];
+        if (p.k0 == 2 && v != 0 && needs_tables) fn = ti.tie_single[slot - 1][v - 1];
         if (v != 0 && slot == 2) lds += ti.BM * ti.BN * 2;
         if (v != 0 && needs_tables) lds += ti.BN * 16;
     }

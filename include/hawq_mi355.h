@@ -106,9 +106,8 @@ typedef struct hawq_conv_args {
                              epilogue (8/8 and 4/4 operand widths, 16-bit residuals); needs ctab
                              (and ctab_id with a second branch).  0 = exact general path (any e in
                              [1,62], any k, ties handled) driven by bias / m / e.
-                             Bit 1 (value 3): additionally every pre-shift k of ctab, ctab_id and
-                             (mq, eq) is 0 - one instruction less per requant (the scalar identity
-                             table (m_id_scalar, e_id_scalar) may still carry one).
+                             Bit 1 (value 3): hint that every pre-shift k of ctab, ctab_id and
+                             (mq, eq) is 0 (checked for eq; currently not used to pick a kernel).
                              Bit 2 (value 5): the tie-freedom proof FAILED for some entry; the kernel
                              then applies the exact round-half-even tie correction to every requant
                              of the call (e in [33,62] and |value << k| < 2^31 still required).     */
