@@ -189,7 +189,7 @@ def main():
                        "scheme": args.scheme, "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
                        "residual_uint16_overflow": overflow,
-                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "shift_free_requant_launches": eng.n_k0, "exact_tie_requant_launches": eng.n_tie,
+                       "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "exact_tie_requant_launches": eng.n_tie,
                        "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
                        "concurrent_sub_batches": eng.chains},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
