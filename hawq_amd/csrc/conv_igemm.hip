@@ -879,7 +879,9 @@ struct BandCfg {
 // travel through LDS untouched and every 16-byte fragment read (32 channels) feeds TWO MFMA K-steps after
 // unpacking in registers (activations zero-extended, weights as value*16, accumulators shifted back by 4 - exact);
 // both operands pair the same channels with the same K-step, so the channel order inside a slice is irrelevant.
-template <class C, bool NIB = false, bool TIE = false>
+// EPI: REQUANT, or RESIDUAL (single branch, uint16 residuals: the 3x3 second conv of a ResNet18/34 basic block).  The
+// residual tile is fetched into the W ring once the K loop has released it (no extra LDS).
+template <class C, bool NIB = false, bool TIE = false, int EPI = HAWQ_EPI_REQUANT>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool prof = (p.dbg & 128) && p.dbgbuf;
@@ -1095,8 +1097,25 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
                 for (int r = 0; r < 16; ++r) acc[c][q][r] >>= 4;
     }
     __syncthreads();
+    if constexpr (EPI == HAWQ_EPI_RESIDUAL) {
+        using S = Stage<C>;
+        static_assert(C::BM * C::BN * 2 <= 3 * C::WSTAGE && C::BM * C::BN <= C::BSTAGES * C::BAND_BYTES, "epilogue tiles alias the rings");
+        constexpr int NWALL = C::NT / 64, PPW = C::BM * S::RCPR / 64 / NWALL;
+        static_assert(PPW * NWALL * 64 == C::BM * S::RCPR, "residual tile pieces");
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int base = (i * NWALL + wave) * 64, idx = base + lane;
+            const int row = idx / S::RCPR, j = idx % S::RCPR;
+            const int grow = (m0 + row < p.M) ? m0 + row : m0;
+            const char *src = (const char *)p.res_in + ((size_t)grow * p.Cout + c0) * 2 + ((j ^ S::rsw(row)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(wring + base * 16), 16, 0, 0);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
     v16i dummy[1][1];
-    epilogue_fast<C, HAWQ_EPI_REQUANT, false, TIE ? 2 : 0>(p, acc, dummy, m0, c0, smem, smem, ctab_lds, consumer);
+    epilogue_fast<C, EPI, false, TIE ? 2 : 0>(p, acc, dummy, m0, c0, smem, wring, ctab_lds, consumer);
     if (prof && blockIdx.x == 8 && t == 0) {
         p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
         p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
@@ -1306,28 +1325,32 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
     if (tile >= NUM_TILES && tile < NUM_TILES + NUM_BAND_TILES) {
         // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 REQUANT layers only
-        struct BandInfo { KernelFn fn[2][2]; int bm, bn, band_px, bstages, lds, nt; };  // fn[hawq4][exact-tie]
-#define BAND_ENTRY(B) {{{conv3x3_band_kernel<B, false, false>, conv3x3_band_kernel<B, false, true>}, {conv3x3_band_kernel<B, true, false>, conv3x3_band_kernel<B, true, true>}}, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
+        struct BandInfo { KernelFn fn[2][2][2]; int bm, bn, band_px, bstages, lds, nt; };  // fn[hawq4][exact-tie][residual]
+#define BAND_FN(B, N, T) {conv3x3_band_kernel<B, N, T, HAWQ_EPI_REQUANT>, conv3x3_band_kernel<B, N, T, HAWQ_EPI_RESIDUAL>}
+#define BAND_ENTRY(B) {{{BAND_FN(B, false, false), BAND_FN(B, false, true)}, {BAND_FN(B, true, false), BAND_FN(B, true, true)}}, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
         static const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2)};
         const BandInfo &bi = kBand[tile - NUM_TILES];
         const int bn = bi.bn;
         const int wo = p.Wo, band_rows = (bi.bm + wo - 1) / wo + 1 + 2;
         const bool nib = a->in_bits == 4 && a->w_bits == 4;
-        const bool ok = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && !dual && fast &&
-                        a->epilogue == HAWQ_EPI_REQUANT && ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) &&
-                        p.Cout % bn == 0 && band_rows * (wo + 2) <= bi.band_px - 4 && a->out_q &&
+        const bool res = a->epilogue == HAWQ_EPI_RESIDUAL;
+        const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q) ||
+                            (res && a->res_in && a->res_in_bits == 16 && (!a->res_out || a->res_out_bits == 16));
+        const bool ok = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && !dual && fast && epi_ok &&
+                        ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) &&
+                        p.Cout % bn == 0 && band_rows * (wo + 2) <= bi.band_px - 4 &&
                         (bi.bstages > 1 || (a->Cin >> (nib ? 7 : 6)) == 1);
         HAWQ_REQUIRE(ok, "hawq_conv2d: tile %d (3x3 band kernel) does not apply to this layer", a->tile);
         static const bool band_attrs = [] {
             bool good = true;
             for (const BandInfo &b : kBand)
-                for (int i = 0; i < 4; ++i)
-                    good &= hipFuncSetAttribute((const void *)b.fn[i >> 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
+                for (int i = 0; i < 8; ++i)
+                    good &= hipFuncSetAttribute((const void *)b.fn[i >> 2][(i >> 1) & 1][i & 1], hipFuncAttributeMaxDynamicSharedMemorySize, b.lds) == hipSuccess;
             return good;
         }();
         HAWQ_REQUIRE(band_attrs, "hawq_conv2d: hipFuncSetAttribute failed for the band kernels");
         const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bn);
-        hipLaunchKernelGGL(bi.fn[nib ? 1 : 0][p.k0 == 2 ? 1 : 0], dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(bi.fn[nib ? 1 : 0][p.k0 == 2 ? 1 : 0][res ? 1 : 0], dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
         HAWQ_CHECK_HIP(hipGetLastError());
         if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
             long long hbuf[4];

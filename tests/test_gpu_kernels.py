@@ -225,6 +225,52 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
     assert lib.load().hawq_conv2d(C.byref(a), None) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (9, 7, 7, 128, 256)])
+@pytest.mark.parametrize("bits,mode", [(8, 1), (8, 5), (4, 1)])
+def test_conv3x3_band_residual(lib, orc, shape, bits, mode):
+    """Band kernels with the RESIDUAL epilogue (3x3 second conv of a basic block): uint16 residual in and out,
+    fused next-QuantAct output; tie-free and exact-tie instantiations; int8 and hawq4 operands."""
+    from hawq_amd.packing import pack_ctab
+    from hawq_amd.quant_utils import requant_table, tables_are_fast
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(7 * h + cin + bits)
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 3, bits, bits)
+    acc = orc.conv2d(x, wt, b, 1, 1)
+    m2, e2 = rand_tables(rng, cout, 2e-5 if bits == 8 else 2e-3, 3e-4 if bits == 8 else 2e-2)
+    assert tables_are_fast(m2, e2, int(np.abs(acc).max()).bit_length() + 1)
+    res = rng.integers(0, 60000, (n, cout, h, w)).astype(np.int64)
+    m1, e1 = requant_table(torch.tensor([0.37 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+    mq, eq = requant_table(torch.tensor([0.0039 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+    ref_res = np.maximum(odyadic(orc, acc, m2, e2) + odyadic(orc, res, m1, e1), 0)
+    assert ref_res.max() < 65536
+    ref_q = odyadic(orc, ref_res, mq, eq, (0, 127))
+    ntiles, nband = lib.load().hawq_conv2d_num_tiles(), lib.load().hawq_conv2d_num_band_tiles()
+    geom = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False)]
+    ran = 0
+    for tile, (bm, bn, band_px, one_chunk) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
+        chunks = cin // 64 if bits == 8 else cin // 128
+        if not (cout % bn == 0 and ((bm + w - 1) // w + 3) * (w + 2) <= band_px - 4 and (chunks == 1 or not one_chunk)
+                and (bits == 8 or cin % 128 == 0)):
+            continue
+        a, keep = conv_args(lib, x, wt, b, 1, 1, bits, bits, tile=tile)
+        keep.update(ctab=dev(pack_ctab(b, m2, e2)), m=dev(m2), e=dev(e2), res=dev(nhwc(res).astype(np.uint16)))
+        flags = torch.zeros(1, dtype=torch.int32, device='cuda')
+        out_res = torch.zeros(ref_res.size, dtype=torch.uint16, device='cuda')
+        out_q = torch.zeros(ref_res.size, dtype=torch.uint8, device='cuda')
+        a.epilogue, a.m, a.e, a.ctab, a.flags = lib.EPI_RESIDUAL, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), flags.data_ptr()
+        a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = keep['res'].data_ptr(), 16, int(m1[0]), int(e1[0])
+        a.res_out, a.res_out_bits = out_res.data_ptr(), 16
+        a.out_q, a.out_bits, a.q_lo, a.q_hi, a.mq, a.eq = out_q.data_ptr(), 8, 0, 127, int(mq[0]), int(eq[0])
+        a.fast_tables = mode
+        lib.call("hawq_conv2d", C.byref(a), stream())
+        got = out_res.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2)
+        assert np.array_equal(got, ref_res), tile
+        assert np.array_equal(unpack_q(out_q, (n, h, w, cout), 8), ref_q), tile
+        assert flags.item() == 0
+        ran += 1
+    assert ran >= 1 or (bits == 4 and cin % 128)
+
+
 @pytest.mark.parametrize("fast", [0, 1, 3, 5])
 @pytest.mark.parametrize("res_bits", [16, 32])
 @pytest.mark.parametrize("dual", [False, True])
