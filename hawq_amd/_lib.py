@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhawq_mi355.so")
+# HAWQ_LIB: another build of the same ABI (A/B measurements of kernel variants); default = the in-tree build
+LIB_PATH = os.environ.get("HAWQ_LIB") or os.path.join(_HERE, "lib", "libhawq_mi355.so")
 
 EPI_RAW, EPI_REQUANT, EPI_RESIDUAL, EPI_DEQUANT = 0, 1, 2, 3
 
