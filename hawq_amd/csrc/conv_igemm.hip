@@ -770,6 +770,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 template <class C, int EPI, bool DUAL, int BITS, int BITS2, bool TIE = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool prof = (p.dbg & 128) && p.dbgbuf;  // HAWQ_DBG=128: cycle stamps of one wave (tools/convprobe.py)
+    const long long t_entry = prof ? (long long)__builtin_readcyclecounter() : 0;
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
     // each XCD a contiguous run of pixel tiles that share the same weight tile in its L2.
     const int tiles_m = (p.M + C::BM - 1) / C::BM;
@@ -816,6 +818,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[c][q][r] = 0;
     }
+    const long long t_begin = prof ? (long long)__builtin_readcyclecounter() : 0;
     constexpr bool ASYNC8 = BITS == 0x88 && (!DUAL || BITS2 == 0x88);
     constexpr bool ASYNC4 = BITS == 0x44 && (!DUAL || BITS2 == 0x44);
     if constexpr (ASYNC8) {
@@ -831,10 +834,15 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
                                   0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
     }
     if (p.dbg & 4) return;
+    const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
     if constexpr (FAST)
         epilogue_fast<C, EPI, DUAL, TIE ? 2 : 0>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
     else
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
+    if (prof && blockIdx.x == 8 && threadIdx.x == 0) {
+        p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
+        p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = 0;
+    }
 }
 
 // =============================================================== 3x3 / stride 1 / pad 1 "band" kernel
@@ -1413,5 +1421,13 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     HAWQ_REQUIRE(attrs_ok, "hawq_conv2d: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipLaunchKernelGGL(fn, dim3(grid), dim3(ti.nt), lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
+    if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
+        long long hbuf[4];
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipMemcpy(hbuf, p.dbgbuf, sizeof(hbuf), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[conv tile %d (%dx%d, %d thr) M=%d K=%dx%dx%d(+%d) Cout=%d epi=%d] grid %d lds %d: prologue %lld | K loop %lld | epilogue %lld cycles\n",
+                tile + 1, ti.BM, ti.BN, ti.nt, p.M, a->KH, a->KW, a->Cin, dual ? a->Cin2 : 0, p.Cout, a->epilogue, grid, lds,
+                hbuf[0], hbuf[1], hbuf[2]);
+    }
     return 0;
 }
