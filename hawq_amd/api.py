@@ -32,3 +32,53 @@ def calibrate(model, images: torch.Tensor):
     freeze_model(model)
     model.invalidate_engine()
     return model
+
+
+# ------------------------------------------------------------------ quantized checkpoints (quant_train.py:665-670)
+_QCKPT_GROUPS = ("convbn_scaling_factor", "fc_scaling_factor", "weight_integer", "bias_integer", "act_scaling_factor")
+
+
+def save_quantized_checkpoint(model, path):
+    """Write ``quantized_checkpoint.pth.tar`` exactly as the reference's ``validate()`` does
+    (quant_train.py:665-670): five dicts of the frozen model's integer weights / biases and scales, keyed by
+    the ``state_dict`` names.  Call after a frozen forward (the buffers are filled by it)."""
+    sd = model.state_dict()
+    torch.save({g: {k: v.detach().cpu() for k, v in sd.items() if g in k} for g in _QCKPT_GROUPS}, path)
+
+
+def load_quantized_checkpoint(model, ckpt, strict: bool = True):
+    """Load a reference ``quantized_checkpoint.pth.tar`` (path or the already-loaded dict) into ``model`` (a
+    ``Q_ResNet*`` with the matching bit configuration applied), freeze it and make its fused engine trust the
+    integer buffers (``IntegerEngine(from_buffers=True)``): no float weights, BN statistics or calibration are
+    needed.  Returns the model.  ``strict`` requires every quantized module to find its entries."""
+    if not isinstance(ckpt, dict):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    missing = [g for g in _QCKPT_GROUPS if g not in ckpt]
+    if missing:
+        raise KeyError(f"not a HAWQ quantized checkpoint: missing {missing}")
+    flat = {}
+    for g in _QCKPT_GROUPS:
+        flat.update(ckpt[g])
+    own = dict(model.named_buffers())
+    own.update(dict(model.named_parameters()))
+    unexpected = [k for k in flat if k not in own]
+    wanted = [k for k in own if any(g in k for g in _QCKPT_GROUPS)]
+    absent = [k for k in wanted if k not in flat]
+    if strict and (unexpected or absent):
+        raise KeyError(f"quantized checkpoint does not match the model: unexpected {unexpected[:3]}..., missing {absent[:3]}...")
+    with torch.no_grad():
+        for k, v in flat.items():
+            if k not in own:
+                continue
+            dst = own[k]
+            v = v.to(device=dst.device, dtype=dst.dtype)
+            if dst.shape == v.shape:
+                dst.copy_(v)
+            else:  # buffers are registered with placeholder shapes until the first frozen forward fills them
+                mod_name, _, attr = k.rpartition(".")
+                setattr(model.get_submodule(mod_name), attr, v.clone())
+    freeze_model(model)
+    model.eval()
+    model.invalidate_engine()
+    model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=True)
+    return model

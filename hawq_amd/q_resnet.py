@@ -121,7 +121,8 @@ class _QResNet(nn.Module):
         """Build (or return the cached) fused integer executor for this frozen network."""
         from .engine import IntegerEngine
         if self._engine is None or kw:
-            self._engine = IntegerEngine(self, **kw)
+            # engine_defaults: set by hawq_amd.api.load_quantized_checkpoint (from_buffers=True)
+            self._engine = IntegerEngine(self, **{**getattr(self, "engine_defaults", {}), **kw})
         return self._engine
 
     def invalidate_engine(self):

@@ -1,0 +1,91 @@
+"""quantized_checkpoint.pth.tar (quant_train.py:665-670): writer / loader of the reference's format.
+CPU: structure round trip, strictness, and - in the build container - the file the LIVE reference writes.
+GPU: a network restored from the checkpoint alone (other float weights, no calibration) gives the same logits."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+GROUPS = ("convbn_scaling_factor", "fc_scaling_factor", "weight_integer", "bias_integer", "act_scaling_factor")
+
+
+def _random_fill(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, b in model.named_buffers():
+            if any(t in k for t in GROUPS):
+                b.copy_(torch.randint(-100, 100, b.shape, generator=g).to(b.dtype))
+
+
+def test_checkpoint_structure_round_trip(tmp_path):
+    from hawq_amd.api import build_quantized_resnet, load_quantized_checkpoint, save_quantized_checkpoint
+    a = build_quantized_resnet("resnet18", "uniform8", seed=1)
+    _random_fill(a, 3)
+    path = str(tmp_path / "quantized_checkpoint.pth.tar")
+    save_quantized_checkpoint(a, path)
+    ck = torch.load(path, map_location="cpu")
+    assert tuple(ck) == GROUPS  # the reference's five dicts, in its order
+    sd = a.state_dict()
+    for g in GROUPS:
+        assert set(ck[g]) == {k for k in sd if g in k} and ck[g]
+    b = build_quantized_resnet("resnet18", "uniform8", seed=2)
+    load_quantized_checkpoint(b, path)
+    assert b.is_frozen() and b.engine_defaults == {"from_buffers": True}
+    for k, v in a.state_dict().items():
+        if any(g in k for g in GROUPS):
+            assert torch.equal(b.state_dict()[k], v), k
+    # a checkpoint of another architecture is refused, not half-loaded
+    c = build_quantized_resnet("resnet50", "uniform8", seed=2)
+    with pytest.raises(KeyError):
+        load_quantized_checkpoint(c, path)
+    with pytest.raises(KeyError):
+        load_quantized_checkpoint(b, {"weight_integer": {}})
+
+
+@pytest.mark.reference
+def test_loads_the_file_the_live_reference_writes(tmp_path):
+    """The reference's own frozen ResNet18 -> its torch.save(...) of quant_train.py:665-670 -> our loader (strict):
+    every key finds its buffer and the integer weights / biases / scales arrive unchanged."""
+    from hawq_amd.api import build_quantized_resnet, load_quantized_checkpoint
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import ref_live
+    q = ref_live.build_reference_model("resnet18", "uniform8", seed=0)
+    ref_live.calibrate_and_freeze(q, synthetic_images(2, seed=0))
+    with torch.no_grad():
+        q(synthetic_images(2, seed=0))  # a frozen forward fills weight_integer / bias_integer / scales
+    sd = q.state_dict()
+    path = str(tmp_path / "quantized_checkpoint.pth.tar")
+    torch.save({g: {k: v for k, v in sd.items() if g in k} for g in GROUPS}, path)  # quant_train.py:665-670 verbatim
+    ours = build_quantized_resnet("resnet18", "uniform8", seed=5)  # different float weights on purpose
+    load_quantized_checkpoint(ours, path, strict=True)
+    mine = ours.state_dict()
+    n = 0
+    for g in GROUPS:
+        for k, v in sd.items():
+            if g in k:
+                assert torch.equal(mine[k].cpu().float().reshape(-1), v.cpu().float().reshape(-1)), k
+                n += 1
+    assert n > 60
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arch,scheme", [("resnet18", "uniform8"), ("resnet50", "uniform4")])
+def test_network_restored_from_checkpoint_alone(tmp_path, arch, scheme):
+    from hawq_amd.api import build_quantized_resnet, calibrate, load_quantized_checkpoint, save_quantized_checkpoint
+    from hawq_amd.skeleton import synthetic_images
+    x = synthetic_images(4, seed=3).cuda()
+    a = build_quantized_resnet(arch, scheme, seed=0).cuda()
+    calibrate(a, synthetic_images(8, seed=0).cuda())
+    ya = a(x).clone()
+    path = str(tmp_path / "quantized_checkpoint.pth.tar")
+    save_quantized_checkpoint(a, path)
+    b = build_quantized_resnet(arch, scheme, seed=9).cuda()  # unrelated float weights, never calibrated
+    load_quantized_checkpoint(b, path)
+    yb = b(x)
+    assert b._engine is not None and b._engine.from_buffers
+    assert torch.equal(ya, yb)
