@@ -95,6 +95,23 @@ def test_network_matches_oracle_on_unseen_inputs(arch, scheme, batch):
     print(f"{arch} {scheme}: max un-clamped residual {mx}")
 
 
+@pytest.mark.parametrize("arch,scheme", [("resnet101", "uniform8"), ("resnet50b", "uniform4"), ("resnet50", "latency_0.5"),
+                                         ("resnet50", "modelsize_0.25"), ("resnet18", "bops_0.5"), ("resnet18", "uniform4")])
+def test_other_architectures_and_schedules_match_oracle(arch, scheme):
+    """The remaining shipped graphs / bit schedules (ResNet101, the stride-on-3x3 ResNet50b, mixed-width
+    schedules with W4A8 / W8A4 layers) against the CPU oracle on unseen inputs."""
+    from hawq_amd.api import calibrate
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import oracle
+    model = H.build_model(arch, scheme)
+    calibrate(model, _images().cuda())
+    x = synthetic_images(3, seed=5) * 1.2
+    ref, _ = oracle.forward_int(oracle.extract_float_state(model), x.numpy())
+    y = model(x.cuda())
+    assert np.array_equal(y.cpu().numpy(), ref)
+    assert not model._engine.overflowed()
+
+
 def test_concurrent_sub_batches_are_bit_identical():
     """The engine may split a batch into 2-3 sub-batches that run concurrently inside one hipGraph (chosen by
     timing at batch >= 48, or forced): logits must not depend on the split (uneven splits included)."""
