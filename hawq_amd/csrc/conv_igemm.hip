@@ -865,8 +865,9 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
 // waves symmetric, a step cost ~3300 cycles for 1536 cycles of MFMA work per SIMD.  So NPROD extra "producer"
 // waves own every LDS-DMA issue and every vmcnt wait; the NW "consumer" waves only read fragments (hand
 // software-pipelined) and issue MFMAs, and the two kinds meet at the per-step barrier.
-template <int BM_, int BN_, int WM_, int WN_, int BAND_PX_, int BSTAGES_, int MINB_, int NPROD_>
+template <int BM_, int BN_, int WM_, int WN_, int BAND_PX_, int BSTAGES_, int MINB_, int NPROD_, int WS_ = 3>
 struct BandCfg {
+    static constexpr int WS = WS_;                            // W ring stages; W(s + WS - 1) is issued during step s
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MINB = MINB_, NPROD = NPROD_;
     static constexpr int NW = WM * WN;                        // consumer (MFMA) waves
     static constexpr int NT = (NW + NPROD) * 64;
@@ -878,7 +879,7 @@ struct BandCfg {
     static constexpr int RG = BN / 16;                        // 16-row groups of a W tap tile
     static constexpr int RPI = RG / ND, WPI = 3 * RPI;        // W row groups / pieces per issuing wave per step
     static constexpr int WTAP = BN * 64, WSTAGE = 3 * WTAP;
-    static constexpr int LDS_BYTES = BSTAGES * BAND_BYTES + 3 * WSTAGE;
+    static constexpr int LDS_BYTES = BSTAGES * BAND_BYTES + WS * WSTAGE;
     static_assert(RG % ND == 0 && (BAND_PX / 16) % ND == 0 && PT >= 1 && CT >= 1, "tile shape");
     static_assert(BM * BN * 2 <= LDS_BYTES, "epilogue staging aliases the rings");
 };
@@ -946,8 +947,8 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
                                              (__attribute__((address_space(3))) void *)(dst + (j & 3) * C::PLANE + (j >> 2) * 1024), 16, 0, 0);
         }
     };
-    auto issue_w = [&](int s, int cc, int kh) {  // the 3 taps of filter row kh, channel slice cc -> ring stage s % 3
-        char *dst = wring + (s % 3) * C::WSTAGE + dw * 1024;
+    auto issue_w = [&](int s, int cc, int kh) {  // the 3 taps of filter row kh, channel slice cc -> ring stage s % WS
+        char *dst = wring + (s % C::WS) * C::WSTAGE + dw * 1024;
         const size_t off = (size_t)(kh * 3) * rowb + (cc << 6);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
@@ -956,9 +957,27 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wsrc[r] + off + (size_t)kw * rowb),
                                                  (__attribute__((address_space(3))) void *)(dst + kw * C::WTAP + r * (C::ND * 1024)), 16, 0, 0);
     };
-    auto issue_step = [&](int s, int cc, int kh) {  // after the barrier of step s: ring stage (s+2)%3 and band stage (cc+1)&1 are free
+    // after barrier #s (which closed step s-1): ring stage (s-1) % WS and band stage (cc+1)&1 are free
+    auto issue_step = [&](int s, int cc, int kh) {
         if (C::BSTAGES > 1 && kh == 0 && cc + 1 < cchunks) issue_band(cc + 1);
-        if (s + 2 < nsteps) issue_w(s + 2, kh + 2 >= 3 ? cc + 1 : cc, kh + 2 >= 3 ? kh - 1 : kh + 2);
+        const int s2 = s + C::WS - 1;
+        if (s2 < nsteps) issue_w(s2, s2 / 3, s2 % 3);
+    };
+    // Before barrier #(s+1) the issuing waves must have seen W(s+2) land.  With WS == 3 that is the W issued in this
+    // very step (everything must have landed); with WS == 4 it was issued one step earlier, and this step's band
+    // prefetch and W(s+3) - younger in program order - may stay in flight.
+    auto wait_step = [&](int s, int cc, int kh) {
+        if (C::WS <= 3) {
+            wait_vmcnt<0>();
+            return;
+        }
+        const bool band_now = C::BSTAGES > 1 && kh == 0 && cc + 1 < cchunks;
+        const bool w_now = s + C::WS - 1 < nsteps;
+        if (band_now) {
+            if (w_now) wait_vmcnt<C::BPI + C::WPI>(); else wait_vmcnt<C::BPI>();
+        } else {
+            if (w_now) wait_vmcnt<C::WPI>(); else wait_vmcnt<0>();
+        }
     };
 
     if (issuer) {
@@ -966,8 +985,9 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.ctab + (size_t)(c0 + dw * 64 + lane) * 4),
                                              (__attribute__((address_space(3))) void *)(ctab_lds + dw * 1024), 16, 0, 0);
         issue_band(0);
-        issue_w(0, 0, 0);
-        issue_w(1, 0, 1);
+#pragma unroll
+        for (int s = 0; s < C::WS - 1; ++s)
+            if (s < nsteps) issue_w(s, s / 3, s % 3);
     }
 
     // ------------------------------------------------------------------ MFMA side (consumer waves)
@@ -1007,7 +1027,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < nsteps; ++s) {
             if (!(p.dbg & 1)) issue_step(s, cc, kh);
-            wait_vmcnt<0>();
+            wait_step(s, cc, kh);
             __builtin_amdgcn_s_barrier();
             if (++kh == 3) kh = 0, ++cc;
         }
@@ -1017,7 +1037,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         unsigned ap[C::PT], wp[C::CT][2];
         // operand bases of step (s, cc, kh); everything inside the batches is base + compile-time immediate
         auto bases = [&](int s, int cc, int kh) {
-            const char *bst = band + (C::BSTAGES > 1 ? (cc & 1) * C::BAND_BYTES : 0) + h * C::PLANE, *wst = wring + (s % 3) * C::WSTAGE;
+            const char *bst = band + (C::BSTAGES > 1 ? (cc & 1) * C::BAND_BYTES : 0) + h * C::PLANE, *wst = wring + (s % C::WS) * C::WSTAGE;
 #pragma unroll
             for (int q = 0; q < C::PT; ++q) {
                 const bool rowok = (unsigned)(yy[q] + kh - 1) < (unsigned)p.Ho;  // else: another image's row / padding -> zeros
@@ -1107,7 +1127,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     __syncthreads();
     if constexpr (EPI == HAWQ_EPI_RESIDUAL) {
         using S = Stage<C>;
-        static_assert(C::BM * C::BN * 2 <= 3 * C::WSTAGE && C::BM * C::BN <= C::BSTAGES * C::BAND_BYTES, "epilogue tiles alias the rings");
+        static_assert(C::BM * C::BN * 2 <= C::WS * C::WSTAGE && C::BM * C::BN <= C::BSTAGES * C::BAND_BYTES, "epilogue tiles alias the rings");
         constexpr int NWALL = C::NT / 64, PPW = C::BM * S::RCPR / 64 / NWALL;
         static_assert(PPW * NWALL * 64 == C::BM * S::RCPR, "residual tile pieces");
 #pragma unroll
@@ -1132,7 +1152,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
 
 using B0 = BandCfg<256, 64, 4, 1, 512, 1, 2, 0>;    // Cin == Cout == 64 (stage 1): 4 waves x (64 px x 64 ch), 2 workgroups per CU
 using B1 = BandCfg<256, 128, 4, 2, 512, 2, 1, 8>;   // 8 MFMA waves x (64 px x 64 ch) + 8 producer waves (LDS-DMA ingest scales with the issuing waves)
-using B2 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8>;   // 8 MFMA waves x (64 px x 32 ch) + 8 producers: twice the workgroups for 14x14 / 7x7
+using B2 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8, 4>;   // 8 MFMA waves x (64 px x 32 ch) + 8 producers: twice the workgroups for 14x14 / 7x7
 constexpr int NUM_BAND_TILES = 3;
 
 using T0 = Cfg<128, 128, 2, 2, 3>;
