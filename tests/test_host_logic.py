@@ -76,6 +76,39 @@ def test_tie_free_proof_is_sound_by_brute_force():
     assert checked > 50
 
 
+def test_exact_tie_correction_equals_round_half_even():
+    """The arithmetic of the fast kernels' exact-tie mode (csrc/common.h:dyadic_tie), restated with Python
+    integers: half-up quotient of t = (v<<k)*m + 2^(e-1), minus one when t is a multiple of 2^e and the quotient is
+    odd.  Must equal round-half-even for EVERY table (tie-free or not), negative values and pre-shifts included;
+    tables_fit_fast is the only precondition."""
+    from hawq_amd.quant_utils import tables_are_fast, tables_fit_fast
+    rng = np.random.default_rng(4)
+    n_ties = n_unproven = 0
+    for _ in range(400):
+        e = int(rng.integers(33, 41))
+        k = int(rng.integers(0, 4))
+        tz = int(rng.integers(0, 31))
+        m = (int(rng.integers(1, 2 ** (31 - tz))) | 1) << tz
+        vbits = int(rng.integers(4, 11))
+        if m >= 2 ** 31 or not tables_fit_fast(np.array([m]), np.array([e | k << 8]), vbits):
+            continue
+        n_unproven += not tables_are_fast(np.array([m]), np.array([e | k << 8]), vbits)
+        for v in range(-(2 ** vbits) + 1, 2 ** vbits):
+            p = (v << k) * m
+            t = p + (1 << (e - 1))
+            q = t >> e                                           # (hi >> s) of the kernel: floor
+            tie = (t & ((1 << e) - 1)) == 0                      # lo == 0 and the low s bits of hi == 0
+            got = q - ((q & 1) if tie else 0)
+            f, rem = p >> e, p - ((p >> e) << e)
+            half = 1 << (e - 1)
+            want = f + (1 if (rem > half or (rem == half and (f & 1))) else 0)
+            assert got == want, (v, m, e, k)
+            n_ties += tie
+    assert n_ties > 100 and n_unproven > 20
+    assert not tables_fit_fast(np.array([1 << 30]), np.array([32]), 10)          # e < 33
+    assert not tables_fit_fast(np.array([1 << 30]), np.array([33 | 9 << 8]), 24)  # 24 + 9 > 31 bits
+
+
 def test_packing_roundtrip_and_layout():
     from hawq_amd.packing import pack_conv_weight, pack_hawq4, pack_stem_weight, unpack_hawq4
     rng = np.random.default_rng(0)

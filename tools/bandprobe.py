@@ -1,4 +1,4 @@
-import ctypes as C, numpy as np, torch, sys, os
+import ctypes as C, numpy as np, torch, sys
 sys.path.insert(0, '/root/repo')
 from hawq_amd import _lib
 from hawq_amd.packing import pack_conv_weight, pack_ctab
