@@ -67,7 +67,7 @@ def test_real_image_fixture():
     assert np.array_equal(y.cpu().numpy(), fx["logits"])
 
 
-@pytest.mark.parametrize("arch,scheme,batch", [("resnet18", "uniform8", 5), ("resnet50", "uniform4", 3),
+@pytest.mark.parametrize("arch,scheme,batch", [("resnet18", "uniform8", 1), ("resnet18", "uniform8", 5), ("resnet50", "uniform4", 3),
                                                 ("resnet50", "bops_0.5", 4), ("resnet50", "uniform8", 16)])
 def test_network_matches_oracle_on_unseen_inputs(arch, scheme, batch):
     """Out-of-calibration inputs (larger magnitude -> un-clamped residuals beyond 32767), batch
