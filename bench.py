@@ -223,7 +223,20 @@ def main():
             out["cpu_baseline"] = None
     if not args.no_extra and world == 1 and rank == 0:
         extra = {}
-        del eng, model
+        # the same workload fed with uint8 NHWC images: table look-up input quantiser, 19 MB instead of
+        # 77 MB of input per batch; logits are bit-identical to the fp32-tensor path (tests/test_gpu_network.py)
+        xu8 = torch.randint(0, 256, (args.batch, 224, 224, 3), dtype=torch.uint8, device=dev)
+        eng.forward_uint8(xu8)
+        n8 = max(10, args.steps // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(eng.stream):
+            for _ in range(n8):
+                eng.run_resident(u8=True)
+        torch.cuda.synchronize()
+        extra[f"{args.arch}_{args.scheme}_b{args.batch}_uint8_input"] = {
+            "images_per_s": round(args.batch * n8 / (time.perf_counter() - t0), 1)}
+        del eng, model, xu8
         torch.cuda.empty_cache()
         for arch, scheme in (("resnet50", "uniform4"), ("resnet50", "bops_0.5"), ("resnet18", "uniform8")):
             if (arch, scheme) == (args.arch, args.scheme):

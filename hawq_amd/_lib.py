@@ -48,6 +48,7 @@ SIGNATURES = {
     "hawq_stem_conv7": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_stem_fused": [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32,
                         i32, vp],
+    "hawq_stem_fused_u8": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "hawq_maxpool3s2_requant": [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "hawq_requant_residual": [vp, i32, i64, vp, i32, i32, i32, i32, i32, vp],
     "hawq_avgpool_requant": [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp],

@@ -150,8 +150,13 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const int8_t *__restric
 constexpr int SF_PW = 40;                       // patch width in pixels (39 used + 1 zero column)
 constexpr int SF_PATCH = 39 * SF_PW * 4;        // bytes per image patch
 
+// U8: the image arrives as uint8 NHWC [N][H][W][Cin] (what an image decoder produces) together with a [3][256] int8
+// table lut[c][u] = QuantAct(normalise_c(u / 255)) built on the host with the reference's own float operations
+// (hawq_amd.engine.input_lut): the input quantiser becomes a table look-up - exact, and the input read shrinks 4x.
+template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
-    const float *__restrict__ x, int N, int Cin, int H, int W, float inv_scale, int in_lo, int in_hi,
+    const float *__restrict__ x, const uint8_t *__restrict__ xu8, const int8_t *__restrict__ lut,
+    int N, int Cin, int H, int W, float inv_scale, int in_lo, int in_hi,
     const int8_t *__restrict__ wgt, const int32_t *__restrict__ bias, const int32_t *__restrict__ m,
     const int32_t *__restrict__ e, int a_lo, int a_hi, int Hc, int Wc, int Hp, int Wp,
     uint16_t *__restrict__ res_out, void *__restrict__ out_q, int out_bits, int mq, int eq, int q_lo, int q_hi,
@@ -167,6 +172,71 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
     const int n0 = (b / bh) * 2;
     const int py0 = by * 8, px0 = bx * 8;
 
+    if constexpr (U8) {
+        // ---- uint8 input: table look-up straight into the LDS patch
+        __shared__ int8_t lut_s[3 * 256];
+        for (int i = t; i < 3 * 256 / 4; i += 256) reinterpret_cast<int *>(lut_s)[i] = reinterpret_cast<const int *>(lut)[i];
+        __syncthreads();
+        constexpr int NG = 2 * 39 * (SF_PW / 4);       // groups of 4 pixels (one 16-B LDS store each)
+        constexpr int GPT = (NG + 255) / 256;          // groups per thread
+        // all byte loads of the thread's groups are issued before any is consumed (the fill is latency-bound otherwise);
+        // coordinates are clamped into the image so every load is legal, out-of-image pixels are zeroed by mask
+        unsigned raw[GPT][3];   // the group's 12 bytes (4 pixels x 3 channels), little-endian
+        unsigned gmask[GPT];
+        int gaddr[GPT];
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            const int g = t + 256 * k;
+            const int gg = g < NG ? g : NG - 1;
+            const int img = gg / (39 * (SF_PW / 4)), rem = gg - img * (39 * (SF_PW / 4));
+            const int r = rem / (SF_PW / 4), c = (rem - r * (SF_PW / 4)) * 4;
+            const int iy = 4 * py0 - 5 + r, ix = 4 * px0 - 5 + c, n = n0 + img;
+            const bool rowok = g < NG && n < N && (unsigned)iy < (unsigned)H && !(dbg & 16);
+            gaddr[k] = img * SF_PATCH + (r * SF_PW + c) * 4;
+            gmask[k] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (rowok && (unsigned)(ix + j) < (unsigned)W && c + j < 39) gmask[k] |= 1u << j;
+            const int nn = n < N ? n : N - 1, yy = min(max(iy, 0), H - 1);
+            const size_t rowoff = ((size_t)nn * H + yy) * W * Cin;
+            if (Cin == 3 && ix >= 0 && ix + 5 < W) {
+                // 4 aligned dwords cover the 12 bytes at any misalignment (and stay inside the row: ix + 5 < W)
+                const size_t b0 = rowoff + (size_t)ix * 3;
+                const unsigned *q4 = reinterpret_cast<const unsigned *>(xu8 + (b0 & ~(size_t)3));
+                const unsigned d0 = q4[0], d1 = q4[1], d2 = q4[2], d3 = q4[3];
+                const unsigned sh = (unsigned)(b0 & 3);
+                raw[k][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                raw[k][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                raw[k][2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            } else {  // image borders / fewer channels: byte loads with clamped coordinates
+                unsigned char b[12];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint8_t *px = xu8 + rowoff + (size_t)min(max(ix + j, 0), W - 1) * Cin;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) b[3 * j + ch] = ch < Cin ? px[ch] : 0;
+                }
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                    raw[k][d] = (unsigned)b[4 * d] | ((unsigned)b[4 * d + 1] << 8) | ((unsigned)b[4 * d + 2] << 16) | ((unsigned)b[4 * d + 3] << 24);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            if (t + 256 * k >= NG) continue;
+            int w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (gmask[k] >> j) & 1;
+                auto byte_at = [&](int i) { return (raw[k][i >> 2] >> (8 * (i & 3))) & 0xffu; };
+                w[j] = ok ? (int)pack4_i8(lut_s[byte_at(3 * j)], Cin > 1 ? lut_s[256 + byte_at(3 * j + 1)] : 0,
+                                          Cin > 2 ? lut_s[512 + byte_at(3 * j + 2)] : 0, 0)
+                          : 0;
+            }
+            v4i o = {w[0], w[1], w[2], w[3]};
+            *reinterpret_cast<v4i *>(patch + gaddr[k]) = o;
+        }
+    } else {
     // ---- quantise the input patch(es) into LDS: q = clamp(rint(fl(1/S) * x))  (quant_utils.py:73-97)
     const size_t plane = (size_t)H * W;
     auto quant1 = [&](float v) {
@@ -225,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
         }
         v4i o = {w[0], w[1], w[2], w[3]};
         *reinterpret_cast<v4i *>(patch + gaddr[k]) = o;
+    }
     }
     __syncthreads();
 
@@ -544,23 +615,50 @@ extern "C" int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, 
     return 0;
 }
 
-extern "C" int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t in_lo,
-                               int32_t in_hi, const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e,
-                               int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq,
-                               int32_t eq, int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream) {
-    HAWQ_REQUIRE(x && wgt && bias && m && e, "hawq_stem_fused: null pointer");
+namespace {
+int stem_fused_launch(const float *x, const uint8_t *xu8, const int8_t *lut, int32_t N, int32_t C, int32_t H, int32_t W,
+                      float inv_scale, int32_t in_lo, int32_t in_hi, const int8_t *wgt, const int32_t *bias, const int32_t *m,
+                      const int32_t *e, int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits,
+                      int32_t mq, int32_t eq, int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream) {
+    HAWQ_REQUIRE((x || (xu8 && lut)) && wgt && bias && m && e, "hawq_stem_fused: null pointer");
     HAWQ_REQUIRE(!fast_tables || ((eq & 0xff) >= 33 && (eq & 0xff) <= 62), "hawq_stem_fused: fast_tables needs eq in [33,62]");
     HAWQ_REQUIRE(res_out || out_q, "hawq_stem_fused: no output requested");
     HAWQ_REQUIRE(C >= 1 && C <= 3 && N > 0 && H >= 7 && W >= 7, "hawq_stem_fused: bad geometry (C <= 3)");
     HAWQ_REQUIRE(!out_q || out_bits == 8 || out_bits == 4, "hawq_stem_fused: out_bits 4/8");
     HAWQ_REQUIRE(a_lo >= -32768 && a_hi <= 65535, "hawq_stem_fused: 16-bit activation range expected");
+    HAWQ_REQUIRE(!lut || (reinterpret_cast<size_t>(lut) & 3) == 0, "hawq_stem_fused_u8: lut must be 4-byte aligned");
     const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;    // conv 7x7 / 2, pad 3
     const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;  // max-pool 3x3 / 2, pad 1
     const long long blocks = (long long)((Wp + 7) / 8) * ((Hp + 7) / 8) * ((N + 1) / 2);
     HAWQ_REQUIRE(blocks < (1ll << 31), "hawq_stem_fused: problem too large");
-    hipLaunchKernelGGL(stem_fused_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, inv_scale,
-                       in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, Hc, Wc, Hp, Wp, res_out, out_q, out_bits, mq, eq, q_lo,
-                       q_hi, fast_tables, getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0);
+    const int dbg = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
+    if (xu8)
+        hipLaunchKernelGGL(stem_fused_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, xu8, lut, N, C, H,
+                           W, inv_scale, in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, Hc, Wc, Hp, Wp, res_out, out_q, out_bits,
+                           mq, eq, q_lo, q_hi, fast_tables, dbg);
+    else
+        hipLaunchKernelGGL(stem_fused_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, xu8, lut, N, C, H,
+                           W, inv_scale, in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, Hc, Wc, Hp, Wp, res_out, out_q, out_bits,
+                           mq, eq, q_lo, q_hi, fast_tables, dbg);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+extern "C" int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t in_lo,
+                               int32_t in_hi, const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e,
+                               int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq,
+                               int32_t eq, int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream) {
+    HAWQ_REQUIRE(x, "hawq_stem_fused: null pointer");
+    return stem_fused_launch(x, nullptr, nullptr, N, C, H, W, inv_scale, in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, res_out,
+                             out_q, out_bits, mq, eq, q_lo, q_hi, fast_tables, stream);
+}
+
+extern "C" int hawq_stem_fused_u8(const uint8_t *x, const int8_t *lut, int32_t N, int32_t C, int32_t H, int32_t W,
+                                  const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e, int32_t a_lo,
+                                  int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq, int32_t eq,
+                                  int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream) {
+    HAWQ_REQUIRE(x && lut, "hawq_stem_fused_u8: null pointer");
+    return stem_fused_launch(nullptr, x, lut, N, C, H, W, 0.f, -128, 127, wgt, bias, m, e, a_lo, a_hi, res_out, out_q, out_bits,
+                             mq, eq, q_lo, q_hi, fast_tables, stream);
 }

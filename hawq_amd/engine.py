@@ -279,9 +279,11 @@ class IntegerEngine:
         self._build_chains(N, H, W, x_view, logits_view)
 
     def _drop_graph(self):
-        if self._graph is not None:
-            _lib.call("hawq_graph_destroy", self._graph)
-            self._graph = None
+        for attr in ("_graph", "_graph_u8"):
+            if getattr(self, attr, None) is not None:
+                _lib.call("hawq_graph_destroy", getattr(self, attr))
+                setattr(self, attr, None)
+        self.x_u8 = None
 
     def _time_graph(self, reps: int = 8) -> float:
         """ms per replay of the captured graph on whatever the input buffer holds (tuning only)."""
@@ -361,6 +363,10 @@ class IntegerEngine:
                                c.w.data_ptr(), c.bias.data_ptr(), st['m'].data_ptr(), st['e'].data_ptr(), st['rng'][0],
                                st['rng'][1], ptr(res), qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0],
                                u0['a_rng'][1], int(st['fast'] and self.fast), sp))
+            # everything after (x, lut, N, C, H, W) of the uint8-input twin of this launch (forward_uint8)
+            self._stem_u8_tail = (c.w.data_ptr(), c.bias.data_ptr(), st['m'].data_ptr(), st['e'].data_ptr(), st['rng'][0],
+                                  st['rng'][1], ptr(res), qa.data_ptr(), u0['a_bits'], u0['mq'], u0['eq'], u0['a_rng'][0],
+                                  u0['a_rng'][1], int(st['fast'] and self.fast), sp)
         keep += [xq, stem16, stem_acc, res, qa]
         h, w = H1, W1
         res_bits_in = 16
@@ -538,20 +544,22 @@ class IntegerEngine:
         self.flags.zero_()  # tuning launches ran on whatever the buffers held; only real forwards may raise the flag
 
     # ------------------------------------------------------------------ execution
-    def _launch_all(self):
+    def _launch_all(self, u8: bool = False):
         if self.subs:  # fork: every chain on its own stream, joined back into self.stream
             fork = torch.cuda.Event()
             fork.record(self.stream)
             for sub in self.subs:
                 sub.stream.wait_event(fork)
-                for op in sub._ops:
-                    op()
+                sub._launch_all(u8)
                 join = torch.cuda.Event()
                 join.record(sub.stream)
                 self.stream.wait_event(join)
             return
-        for op in self._ops:
-            op()
+        for i, op in enumerate(self._ops):
+            if u8 and i == 0:
+                self._stem_u8_op()
+            else:
+                op()
 
     def __call__(self, x):
         if not x.is_cuda:
@@ -569,22 +577,79 @@ class IntegerEngine:
         cur.wait_stream(self.stream)
         return self.logits
 
-    def run_resident(self):
-        """One forward over ``self.x_in`` (already resident) on ``self.stream``; returns nothing."""
+    def run_resident(self, u8: bool = False):
+        """One forward over ``self.x_in`` (or, ``u8``, over ``self.x_u8``) already resident, on ``self.stream``."""
         if self.use_graph:
-            if self._graph is None:
-                self._launch_all()  # warm-up outside capture (module loading, first-touch)
+            attr = "_graph_u8" if u8 else "_graph"
+            if getattr(self, attr, None) is None:
+                self._launch_all(u8)  # warm-up outside capture (module loading, first-touch)
                 torch.cuda.synchronize(self.dev)
                 _lib.call("hawq_graph_begin", self.stream.cuda_stream)
                 try:
-                    self._launch_all()
+                    self._launch_all(u8)
                 finally:
                     g = C.c_void_p()
                     _lib.call("hawq_graph_end", self.stream.cuda_stream, C.byref(g))
-                self._graph = g
-            _lib.call("hawq_graph_launch", self._graph, self.stream.cuda_stream)
+                setattr(self, attr, g)
+            _lib.call("hawq_graph_launch", getattr(self, attr), self.stream.cuda_stream)
         else:
-            self._launch_all()
+            self._launch_all(u8)
+
+    # ------------------------------------------------------------------ uint8 image input (quant_train.py:432-440)
+    def input_lut(self, mean, std) -> torch.Tensor:
+        """int8 [3][256]: lut[c][u] = QuantAct_input(Normalize_c(ToTensor(u))) with the reference pipeline's own float32
+        operations on the host (torchvision ToTensor ``u.float().div(255)``, Normalize ``sub(mean).div(std)``,
+        then ``clamp(rint(fl(1/S) * v))``, quant_utils.py:73-97) - so the table look-up in the stem kernel is
+        bit-identical to quantising the normalised fp32 tensor."""
+        u = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255)
+        mean32, std32 = torch.as_tensor(mean, dtype=torch.float32), torch.as_tensor(std, dtype=torch.float32)
+        v = (u.view(1, 256) - mean32.view(3, 1)) / std32.view(3, 1)
+        inv = torch.tensor(self.P['inv_s_in'], dtype=torch.float32)
+        return torch.round(inv * v).clamp(-128, 127).to(torch.int8).contiguous()
+
+    def _ensure_u8(self, N, H, W, x_view=None, lut=None):
+        if self.subs:
+            if getattr(self, "x_u8", None) is None or self.x_u8.shape[0] != N:
+                self.x_u8 = torch.empty(N, H, W, 3, dtype=torch.uint8, device=self.dev)
+                self.lut_dev = torch.zeros(3, 256, dtype=torch.int8, device=self.dev)
+                b0 = 0
+                for sub in self.subs:
+                    n = sub._batch[0]
+                    sub._ensure_u8(n, H, W, self.x_u8[b0:b0 + n], self.lut_dev)
+                    b0 += n
+            return
+        if x_view is None:
+            if getattr(self, "x_u8", None) is not None and self.x_u8.shape[0] == N:
+                return
+            x_view = torch.empty(N, H, W, 3, dtype=torch.uint8, device=self.dev)
+            lut = torch.zeros(3, 256, dtype=torch.int8, device=self.dev)
+        if not hasattr(self, "_stem_u8_tail"):
+            raise RuntimeError("uint8 input needs the fused stem (not available with keep_accumulators / HAWQ_UNFUSED_STEM)")
+        self.x_u8, self.lut_dev = x_view, lut
+        self._stem_u8_op = partial(_lib.call, "hawq_stem_fused_u8", x_view.data_ptr(), lut.data_ptr(), N, 3, H, W,
+                                   *self._stem_u8_tail)
+
+    def forward_uint8(self, x_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """uint8 NHWC images [N,H,W,3] (decoder output, after resize / crop) -> fp32 logits.  Equivalent, bit for bit,
+        to ``self(normalised fp32 NCHW tensor)`` as the reference's data pipeline would have built it; the fp32 tensor
+        (4x the bytes) never exists."""
+        if not x_u8.is_cuda or x_u8.dtype != torch.uint8 or x_u8.dim() != 4 or x_u8.shape[3] != 3:
+            raise ValueError("expected a uint8 NHWC [N,H,W,3] tensor on the MI355X")
+        N, H, W, _ = x_u8.shape
+        if self._batch != (N, H, W):
+            self._build(N, H, W)
+        self._ensure_u8(N, H, W)
+        key = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+        cur = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if getattr(self, "_lut_key", None) != key:
+                self.lut_dev.copy_(self.input_lut(mean, std).to(self.dev), non_blocking=False)
+                self._lut_key = key
+            self.x_u8.copy_(x_u8, non_blocking=True)
+            self.run_resident(u8=True)
+        cur.wait_stream(self.stream)
+        return self.logits
 
     def profile_ops(self, repeats: int = 5):
         """Per-launch durations (ms, median of ``repeats``) measured with HIP events around each
@@ -623,7 +688,6 @@ class IntegerEngine:
 
     def __del__(self):
         try:
-            if self._graph is not None:
-                _lib.call("hawq_graph_destroy", self._graph)
+            self._drop_graph()
         except Exception:
             pass

@@ -145,6 +145,15 @@ int hawq_stem_fused(const float *x, int32_t N, int32_t C, int32_t H, int32_t W, 
                     int32_t a_lo, int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq,
                     int32_t eq, int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream);
 
+/* Same kernel fed by uint8 NHWC images [N][H][W][C] (decoder output) and a host-built table
+ * lut[c][u] = clamp(rint(fl(1/S) * normalise_c(u / 255))), c < 3, u < 256 (int8, 4-byte aligned): the input
+ * QuantAct (quant_modules.py:271-274) of the normalised image becomes a look-up, bit-identical to quantising the
+ * fp32 tensor that torchvision's ToTensor + Normalize (quant_train.py:432-440) would have produced.            */
+int hawq_stem_fused_u8(const uint8_t *x, const int8_t *lut, int32_t N, int32_t C, int32_t H, int32_t W,
+                       const int8_t *wgt, const int32_t *bias, const int32_t *m, const int32_t *e, int32_t a_lo,
+                       int32_t a_hi, uint16_t *res_out, void *out_q, int32_t out_bits, int32_t mq, int32_t eq,
+                       int32_t q_lo, int32_t q_hi, int32_t fast_tables, void *stream);
+
 /* nn.MaxPool2d(3,2,1) (q_resnet.py:93,119) on the requantised stem output + the first
  * unit's QuantAct: in [N][H][W][C] uint16 -> res_out [N][Ho][Wo][C] uint16 and
  * out_q = clamp(dyadic(res, mq, eq)) int8/hawq4 (either may be NULL). */

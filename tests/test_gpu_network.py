@@ -112,6 +112,28 @@ def test_other_architectures_and_schedules_match_oracle(arch, scheme):
     assert not model._engine.overflowed()
 
 
+@pytest.mark.parametrize("batch", [3, 50])
+def test_uint8_image_input_equals_the_normalised_fp32_path(batch):
+    """forward_uint8 (uint8 NHWC images + host-built look-up table in the stem kernel) against the same engine fed
+    with the fp32 tensor the reference's pipeline builds on the host (ToTensor + Normalize, quant_train.py:432-440);
+    batch 50 runs as concurrent sub-batches.  Also a second (mean, std) to see the table refresh."""
+    from hawq_amd.api import calibrate
+    from hawq_amd.engine import IntegerEngine
+    model = H.build_model("resnet50", "uniform8")
+    calibrate(model, _images().cuda())
+    g = torch.Generator().manual_seed(batch)
+    xu8 = torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=g)
+    eng = IntegerEngine(model)
+    for mean, std in (((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), ((0.5, 0.4, 0.45), (0.25, 0.2, 0.3))):
+        t = xu8.permute(0, 3, 1, 2).to(torch.float32).div(255)                       # ToTensor
+        t = t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))  # Normalize
+        ref = eng(t.cuda()).clone()
+        y = eng.forward_uint8(xu8.cuda(), mean, std).clone()
+        assert torch.equal(y, ref)
+        assert torch.equal(eng.forward_uint8(xu8.cuda(), mean, std), ref)  # graph replay
+    assert ref.abs().max() > 0 and not eng.overflowed()
+
+
 def test_concurrent_sub_batches_are_bit_identical():
     """The engine may split a batch into 2-3 sub-batches that run concurrently inside one hipGraph (chosen by
     timing at batch >= 48, or forced): logits must not depend on the split (uneven splits included)."""
