@@ -82,3 +82,39 @@ def load_quantized_checkpoint(model, ckpt, strict: bool = True):
     model.invalidate_engine()
     model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=True)
     return model
+
+
+# ------------------------------------------------------------------ float QAT checkpoints (quant_train.py:303-314)
+def load_checkpoint(model, ckpt, freeze: bool = True):
+    """Load a HAWQ ``checkpoint.pth.tar`` / ``model_best.pth.tar`` (path or loaded dict) the way
+    ``quant_train.py --resume --resume-quantize`` does (quant_train.py:303-314): take ``['state_dict']``, drop
+    ``num_batches_tracked`` / ``weight_integer`` / ``bias_integer`` entries, strip the DataParallel ``module.`` prefix,
+    ``load_state_dict(strict=False)``.  The checkpoint carries float weights, BN statistics and the activation ranges
+    (``x_min`` / ``x_max``) of QAT, so no calibration is needed; with ``freeze`` the model is frozen for inference as
+    ``validate()`` does (quant_train.py:636).  Returns (model, missing_keys, unexpected_keys)."""
+    if not isinstance(ckpt, dict):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    kept = {}
+    for key, value in sd.items():
+        if "num_batches_tracked" in key or "weight_integer" in key or "bias_integer" in key:
+            continue
+        kept[key.replace("module.", "")] = value
+    own = model.state_dict()
+    # buffers whose placeholder shape differs (filled by the first frozen forward) cannot go through load_state_dict
+    direct = {k: v for k, v in kept.items() if k in own and own[k].shape == v.shape}
+    result = model.load_state_dict(direct, strict=False)
+    with torch.no_grad():
+        for k, v in kept.items():
+            if k in own and own[k].shape != v.shape:
+                mod_name, _, attr = k.rpartition(".")
+                setattr(model.get_submodule(mod_name), attr, v.to(device=own[k].device, dtype=own[k].dtype).clone())
+    unexpected = [k for k in kept if k not in own]
+    missing = [k for k in result.missing_keys
+               if not any(t in k for t in ("num_batches_tracked", "weight_integer", "bias_integer"))
+               and k not in kept]
+    if freeze:
+        freeze_model(model)
+        model.eval()
+    model.invalidate_engine()
+    return model, missing, unexpected

@@ -73,6 +73,48 @@ def test_loads_the_file_the_live_reference_writes(tmp_path):
     assert n > 60
 
 
+@pytest.mark.reference
+def test_loads_a_float_checkpoint_of_the_live_reference():
+    """checkpoint.pth.tar as quant_train.py writes it ({'state_dict': DataParallel-prefixed}) from the reference's
+    calibrated ResNet18 -> hawq_amd.api.load_checkpoint: every float weight, BN statistic and activation range arrives,
+    nothing is missing or unexpected (same module / buffer names)."""
+    from hawq_amd.api import build_quantized_resnet, load_checkpoint
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import ref_live
+    q = ref_live.build_reference_model("resnet18", "uniform8", seed=0)
+    with torch.no_grad():
+        q(synthetic_images(2, seed=0))  # un-frozen forward: QuantAct ranges initialise (quant_modules.py:247-250)
+    sd = q.state_dict()
+    ckpt = {"epoch": 1, "arch": "resnet18", "state_dict": {"module." + k: v for k, v in sd.items()}, "best_acc1": 0.0}
+    ours = build_quantized_resnet("resnet18", "uniform8", seed=5)
+    ours, missing, unexpected = load_checkpoint(ours, ckpt)
+    assert not missing and not unexpected
+    assert ours.is_frozen()
+    mine = ours.state_dict()
+    n = 0
+    for k, v in sd.items():
+        if any(t in k for t in ("num_batches_tracked", "weight_integer", "bias_integer")):
+            continue
+        assert torch.equal(mine[k].cpu().reshape(-1).float(), v.cpu().reshape(-1).float()), k
+        n += 1
+    assert n > 150
+
+
+@pytest.mark.gpu
+def test_float_checkpoint_round_trip_reproduces_logits():
+    from hawq_amd.api import build_quantized_resnet, calibrate, load_checkpoint
+    from hawq_amd.skeleton import synthetic_images
+    x = synthetic_images(4, seed=3).cuda()
+    a = build_quantized_resnet("resnet50", "bops_0.5", seed=0).cuda()
+    calibrate(a, synthetic_images(8, seed=0).cuda())
+    ya = a(x).clone()
+    ckpt = {"state_dict": {"module." + k: v.detach().cpu() for k, v in a.state_dict().items()}}
+    b = build_quantized_resnet("resnet50", "bops_0.5", seed=9).cuda()
+    b, missing, unexpected = load_checkpoint(b, ckpt)
+    assert not missing and not unexpected
+    assert torch.equal(b(x), ya)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("arch,scheme", [("resnet18", "uniform8"), ("resnet50", "uniform4")])
 def test_network_restored_from_checkpoint_alone(tmp_path, arch, scheme):
