@@ -118,3 +118,27 @@ def load_checkpoint(model, ckpt, freeze: bool = True):
         model.eval()
     model.invalidate_engine()
     return model, missing, unexpected
+
+
+# ------------------------------------------------------------------ evaluation loop (quant_train.py:625-674)
+def validate(model, loader, uint8: bool = False, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), device="cuda"):
+    """Top-1 / top-5 accuracy (percent) of a frozen ``Q_ResNet*`` over ``loader`` = iterable of (images, target):
+    the body of the reference's ``validate()`` (freeze, eval, no_grad, ``accuracy(output, target, topk=(1, 5))``,
+    sample-weighted averages).  ``images`` are normalised fp32 NCHW batches as the reference's pipeline produces, or -
+    ``uint8`` - raw uint8 NHWC batches that go through the look-up-table input quantiser (``forward_uint8``).
+    Returns (top1, top5, n_images)."""
+    freeze_model(model)
+    model.eval()
+    top1 = top5 = 0.0
+    n = 0
+    with torch.no_grad():
+        for images, target in loader:
+            images = images.to(device, non_blocking=True)
+            target = target.to(device, non_blocking=True)
+            output = model.engine().forward_uint8(images, mean, std) if uint8 else model(images)
+            _, pred = output.topk(5, 1, True, True)
+            correct = pred.t().eq(target.view(1, -1).expand(5, -1))
+            top1 += float(correct[:1].reshape(-1).float().sum())
+            top5 += float(correct[:5].reshape(-1).float().sum())
+            n += int(target.size(0))
+    return 100.0 * top1 / max(n, 1), 100.0 * top5 / max(n, 1), n

@@ -284,6 +284,7 @@ class IntegerEngine:
                 _lib.call("hawq_graph_destroy", getattr(self, attr))
                 setattr(self, attr, None)
         self.x_u8 = None
+        self._lut_key = None  # the look-up table lives in buffers that a rebuild replaces
 
     def _time_graph(self, reps: int = 8) -> float:
         """ms per replay of the captured graph on whatever the input buffer holds (tuning only)."""
@@ -612,6 +613,7 @@ class IntegerEngine:
             if getattr(self, "x_u8", None) is None or self.x_u8.shape[0] != N:
                 self.x_u8 = torch.empty(N, H, W, 3, dtype=torch.uint8, device=self.dev)
                 self.lut_dev = torch.zeros(3, 256, dtype=torch.int8, device=self.dev)
+                self._lut_key = None
                 b0 = 0
                 for sub in self.subs:
                     n = sub._batch[0]
@@ -623,6 +625,7 @@ class IntegerEngine:
                 return
             x_view = torch.empty(N, H, W, 3, dtype=torch.uint8, device=self.dev)
             lut = torch.zeros(3, 256, dtype=torch.int8, device=self.dev)
+            self._lut_key = None
         if not hasattr(self, "_stem_u8_tail"):
             raise RuntimeError("uint8 input needs the fused stem (not available with keep_accumulators / HAWQ_UNFUSED_STEM)")
         self.x_u8, self.lut_dev = x_view, lut

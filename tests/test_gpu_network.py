@@ -134,6 +134,36 @@ def test_uint8_image_input_equals_the_normalised_fp32_path(batch):
     assert ref.abs().max() > 0 and not eng.overflowed()
 
 
+def test_validate_loop_fp32_and_uint8():
+    """hawq_amd.api.validate (the body of quant_train.py:validate) on a synthetic labelled set: labels are the
+    network's own top-1 on half of the images and its lowest-ranked class on the rest -> exactly 50 % / 50 %; the
+    uint8 pipeline must count the same images."""
+    from hawq_amd.api import calibrate, validate
+    model = H.build_model("resnet18", "uniform8")
+    calibrate(model, _images().cuda())
+    g = torch.Generator().manual_seed(1)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    batches_u8 = [torch.randint(0, 256, (n, 224, 224, 3), dtype=torch.uint8, generator=g) for n in (6, 4)]
+    def norm(xu8):
+        t = xu8.permute(0, 3, 1, 2).to(torch.float32).div(255)
+        return t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))
+    fp32, u8 = [], []
+    for xu8 in batches_u8:
+        logits = model(norm(xu8).cuda())
+        top = logits.topk(5, 1, True, True)  # same op, same device as validate(): identical tie-breaking
+        target = top.indices[:, 0].clone()
+        worst = logits.argmin(1)
+        assert (logits.gather(1, worst.view(-1, 1)).view(-1) < top.values[:, 4]).all()
+        target[::2] = worst[::2]  # every other label is the lowest-ranked class: wrong for top-1 and top-5
+        target = target.cpu()
+        fp32.append((norm(xu8), target))
+        u8.append((xu8, target))
+    t1, t5, n = validate(model, fp32)
+    assert (t1, t5, n) == (50.0, 50.0, 10)
+    assert validate(model, u8, uint8=True) == (50.0, 50.0, 10)   # batch shape changes between the two batches:
+    assert validate(model, u8, uint8=True) == (50.0, 50.0, 10)   # the rebuilt engine must re-upload its table
+
+
 def test_concurrent_sub_batches_are_bit_identical():
     """The engine may split a batch into 2-3 sub-batches that run concurrently inside one hipGraph (chosen by
     timing at batch >= 48, or forced): logits must not depend on the split (uneven splits included)."""
