@@ -858,7 +858,8 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
 //               pixels per LDS cycle) is conflict-free WITHOUT a swizzle and every (tap, k-half) address is
 //               base + immediate: the inner loop carries no address arithmetic.  The last 4 entries of each
 //               plane are zeros: taps whose row lies outside the pixel's image read those.
-//   W ring    : 3 stages x (3 taps x BN x 64 B), one stage per (slice, filter row) step, issued two steps ahead
+//   W ring    : WS (3 or 4) stages x (3 taps x BN x 64 B), one stage per (slice, filter row) step, issued WS - 1
+//               steps ahead
 // Wave specialisation (NPROD > 0).  Measured on gfx950 (tools/ubench/mfma_rate.hip, HAWQ_DBG=128 stamps):
 // the matrix pipe serves the OLDEST ready wave of a SIMD first, an LDS-DMA issue blocks its wave for 60-150
 // cycles, and hipcc cannot overlap LDS reads with MFMAs once LDS-DMA is in the loop (see lds_read16).  With all
