@@ -602,11 +602,8 @@ class IntegerEngine:
         operations on the host (torchvision ToTensor ``u.float().div(255)``, Normalize ``sub(mean).div(std)``,
         then ``clamp(rint(fl(1/S) * v))``, quant_utils.py:73-97) - so the table look-up in the stem kernel is
         bit-identical to quantising the normalised fp32 tensor."""
-        u = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255)
-        mean32, std32 = torch.as_tensor(mean, dtype=torch.float32), torch.as_tensor(std, dtype=torch.float32)
-        v = (u.view(1, 256) - mean32.view(3, 1)) / std32.view(3, 1)
-        inv = torch.tensor(self.P['inv_s_in'], dtype=torch.float32)
-        return torch.round(inv * v).clamp(-128, 127).to(torch.int8).contiguous()
+        from .quant_utils import input_quant_lut
+        return input_quant_lut(self.P['inv_s_in'], mean, std)
 
     def _ensure_u8(self, N, H, W, x_view=None, lut=None):
         if self.subs:

@@ -124,6 +124,18 @@ def tables_are_fast(m, ek, vbits, allow_shift=True) -> bool:
     return bool(((m == 0) | (tz <= e - 1 - k - vb)).all())
 
 
+def input_quant_lut(inv_scale: float, mean, std, lo: int = -128, hi: int = 127) -> torch.Tensor:
+    """int8 [3][256]: lut[c][u] = clamp(rint(fl(1/S) * Normalize_c(ToTensor(u)))) with the reference pipeline's own
+    float32 operations on the host - torchvision ToTensor ``u.float().div(255)``, Normalize ``sub(mean).div(std)``
+    (quant_train.py:432-440), then the input QuantAct (quant_utils.py:73-97).  A table look-up of a uint8 pixel is
+    therefore bit-identical to quantising the normalised fp32 tensor."""
+    u = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255)
+    mean32, std32 = torch.as_tensor(mean, dtype=torch.float32), torch.as_tensor(std, dtype=torch.float32)
+    v = (u.view(1, 256) - mean32.view(3, 1)) / std32.view(3, 1)
+    inv = torch.tensor(float(inv_scale), dtype=torch.float32)
+    return torch.round(inv * v).clamp(lo, hi).to(torch.int8).contiguous()
+
+
 # --------------------------------------------------------------------- quantise-from-float
 def linear_quantize(input, scale, zero_point, inplace=False):
     """round(1/scale * x + zp) with the reference's broadcasting rules (quant_utils.py:73-97).

@@ -109,6 +109,25 @@ def test_exact_tie_correction_equals_round_half_even():
     assert not tables_fit_fast(np.array([1 << 30]), np.array([33 | 9 << 8]), 24)  # 24 + 9 > 31 bits
 
 
+def test_uint8_input_table_equals_quantising_the_normalised_image():
+    """hawq_amd.quant_utils.input_quant_lut against the oracle's input quantiser (oracle/hawq_oracle.c:hq_quantize_f32)
+    applied to a real ToTensor + Normalize tensor: every one of the 3 x 256 pixel values."""
+    from hawq_amd.quant_utils import input_quant_lut
+    from oracle import oracle as orc
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    img = torch.arange(256, dtype=torch.uint8).view(1, 256, 1, 1).expand(1, 256, 1, 3).contiguous()  # NHWC, all values
+    t = img.permute(0, 3, 1, 2).to(torch.float32).div(255)                                            # ToTensor
+    t = t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))          # Normalize
+    clamped = False
+    for s_in in (0.0207, 2.64 / 127, 0.0123456):
+        inv = float(np.float32(1.0) / np.float32(s_in))                       # fl(1/S), as the engine passes it
+        want = orc.quantize_f32(t.numpy(), np.float32(s_in), 8).reshape(3, 256)
+        got = input_quant_lut(inv, mean, std).numpy().astype(np.int64)
+        assert np.array_equal(got, want)
+        clamped |= got.min() == -128 or got.max() == 127
+    assert clamped  # at least one scale drives the table into the clamp
+
+
 def test_packing_roundtrip_and_layout():
     from hawq_amd.packing import pack_conv_weight, pack_hawq4, pack_stem_weight, unpack_hawq4
     rng = np.random.default_rng(0)
