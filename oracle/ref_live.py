@@ -105,7 +105,9 @@ def build_reference_model(arch: str, scheme: str, seed: int = 0):
 
     qr, qm, _ = load_reference()
     fl = init_synthetic(build_float_resnet(arch), seed)
-    q = {"resnet18": qr.q_resnet18, "resnet50": qr.q_resnet50, "resnet101": qr.q_resnet101}[arch](fl)
+    # quant_train.py:155-158 (quantize_arch_dict): resnet50b shares q_resnet50
+    q = {"resnet18": qr.q_resnet18, "resnet50": qr.q_resnet50, "resnet50b": qr.q_resnet50,
+         "resnet101": qr.q_resnet101}[arch](fl)
     apply_bit_config(q, get_bit_config(arch, scheme))
     q.eval()
     return q

@@ -182,7 +182,7 @@ def kat_modules(qm):
     return out
 
 
-def net_fixture(arch, scheme, batch, image=None):
+def net_fixture(arch, scheme, batch, image=None, light=False):
     from oracle import oracle  # only used for its IEEE host-prep, to express weight_integer as patches
 
     qr, qm, qu = ref_live.load_reference()
@@ -242,7 +242,7 @@ def net_fixture(arch, scheme, batch, image=None):
         w_ieee, _ = oracle.quantize_weight(w_f, cb["bits"])
         for idx in np.argwhere(wi.reshape(-1) != w_ieee.reshape(-1)).reshape(-1):
             patches.append((li, int(idx), int(wi.reshape(-1)[idx])))
-        if name in ("stage4.unit2.quant_convbn1", "stage1.unit1.quant_convbn1"):
+        if not light and name in ("stage4.unit2.quant_convbn1", "stage1.unit1.quant_convbn1"):
             out["acc_full." + name] = acc.astype(np.int32)
     out["conv_scale"] = np.concatenate(scales).astype(np.float32)
     out["conv_bias"] = np.concatenate(biases)
@@ -258,13 +258,29 @@ def net_fixture(arch, scheme, batch, image=None):
     return out
 
 
+EXTRA = (("resnet101", "uniform8", 2), ("resnet50b", "uniform4", 2), ("resnet50", "latency_0.5", 2),
+         ("resnet50", "modelsize_0.25", 2))
+
+
 def main():
     qr, qm, qu = ref_live.load_reference()
+    if "--extra-only" in sys.argv:
+        for arch, scheme, b in EXTRA:
+            fx = net_fixture(arch, scheme, b, light=True)
+            np.savez_compressed(os.path.join(HERE, f"net_{arch}_{scheme}_b{b}.npz"), **fx)
+            print(arch, scheme, "acc_absmax", int(fx["acc_absmax"]), "wpatches", len(fx["conv_wpatch"]), flush=True)
+        return
     np.savez_compressed(os.path.join(HERE, "kat_functions.npz"), **kat_functions(qu))
     np.savez_compressed(os.path.join(HERE, "kat_modules.npz"), **kat_modules(qm))
     for arch, scheme, b in (("resnet18", "uniform8", 2), ("resnet18", "uniform4", 2), ("resnet18", "bops_0.5", 2),
                             ("resnet50", "uniform8", 2), ("resnet50", "uniform4", 2), ("resnet50", "bops_0.5", 2)):
         fx = net_fixture(arch, scheme, b)
+        np.savez_compressed(os.path.join(HERE, f"net_{arch}_{scheme}_b{b}.npz"), **fx)
+        print(arch, scheme, "acc_absmax", int(fx["acc_absmax"]), "wpatches", len(fx["conv_wpatch"]), flush=True)
+    # further shipped graphs / schedules (ResNet101, the stride-on-3x3 ResNet50b, mixed-width schedules): "light"
+    # fixtures without the two full accumulator tensors
+    for arch, scheme, b in EXTRA:
+        fx = net_fixture(arch, scheme, b, light=True)
         np.savez_compressed(os.path.join(HERE, f"net_{arch}_{scheme}_b{b}.npz"), **fx)
         print(arch, scheme, "acc_absmax", int(fx["acc_absmax"]), "wpatches", len(fx["conv_wpatch"]), flush=True)
     # the one real-image fixture the reference ships (tvm_benchmark/models/input_image_batch_1.npy, NHWC)

@@ -9,6 +9,9 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NET_CONFIGS = [("resnet18", "uniform8"), ("resnet18", "uniform4"), ("resnet18", "bops_0.5"),
                ("resnet50", "uniform8"), ("resnet50", "uniform4"), ("resnet50", "bops_0.5")]
+# "light" fixtures (no full accumulator tensors): further shipped graphs / schedules
+NET_CONFIGS_EXTRA = [("resnet101", "uniform8"), ("resnet50b", "uniform4"), ("resnet50", "latency_0.5"),
+                     ("resnet50", "modelsize_0.25")]
 
 
 def load(name):
@@ -101,4 +104,10 @@ def load_reference_integer_ckpt(model, fx):
         m.convbn_scaling_factor = torch.from_numpy(fx["conv_scale"][off:off + co].copy()).to(dev)
         m.bias_integer = torch.from_numpy(fx["conv_bias"][off:off + co].astype(np.float32)).to(dev)
         off += co
+    # the classifier: its bias integers depend on the (reference's) scale of quant_act_output
+    fc = model.quant_output
+    dev = fc.weight_integer.device
+    assert np.array_equal(digest(fc.weight_integer.detach().cpu().numpy()), fx["fc_wdigest"])
+    fc.fc_scaling_factor = torch.from_numpy(np.asarray(fx["fc_scale"], np.float32).reshape(-1).copy()).to(dev)
+    fc.bias_integer = torch.from_numpy(np.asarray(fx["fc_bias"]).astype(np.float32).reshape(-1)).to(dev)
     return npatch

@@ -137,7 +137,7 @@ def _build_state(arch, scheme):
     return state_from_skeleton(fl, arch, get_bit_config(arch, scheme))
 
 
-@pytest.mark.parametrize("arch,scheme", H.NET_CONFIGS)
+@pytest.mark.parametrize("arch,scheme", H.NET_CONFIGS + H.NET_CONFIGS_EXTRA)
 def test_network_forward_matches_reference(arch, scheme):
     """Oracle integer forward == live reference logits, accumulators and frozen ranges."""
     import torch
