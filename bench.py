@@ -196,6 +196,9 @@ def main():
                          "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "one hipGraph launch = whole forward of one batch",
                          "gpu_ms_per_launch": round(gpu_ms, 4), "algorithmic_bytes_per_launch": alg,
+                         # what the fused plan must move at minimum (hawq_amd/roofline.py:fused_plan_table); "traffic"
+                         # is its measured counterpart
+                         "fused_plan_bytes_per_launch": roofline.fused_plan_bytes(args.arch, args.scheme, args.batch),
                          "mfma_frac": round(2 * macs / (gpu_ms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)},
         }
         if (not args.no_extra or args.per_op) and world == 1:

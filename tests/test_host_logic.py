@@ -128,6 +128,25 @@ def test_uint8_input_table_equals_quantising_the_normalised_image():
     assert clamped  # at least one scale drives the table into the clamp
 
 
+def test_fused_plan_byte_model():
+    """hawq_amd.roofline.fused_plan_table: one row per launch of the engine's plan, the same MACs as the canonical
+    layer table, fewer bytes than it (no separate QuantAct passes, no int32 identity accumulators, no 112^2 stem
+    intermediate), and within 15 % of the HBM traffic measured with PMC counters (profiles/traffic.json)."""
+    import json
+    from hawq_amd import roofline as R
+    for arch, scheme, launches in (("resnet50", "uniform8", 51), ("resnet50", "uniform4", 51), ("resnet18", "uniform8", 19),
+                                   ("resnet101", "uniform8", 102)):
+        t = R.fused_plan_table(arch, scheme)
+        assert len(t) == launches
+        assert sum(r["macs"] for r in t) == sum(r["macs"] for r in R.layer_table(arch, scheme))
+        assert R.fused_plan_bytes(arch, scheme, 128) < 0.65 * R.algorithmic_bytes(arch, scheme, 128)
+    assert R.fused_plan_bytes("resnet50", "uniform4", 128) < 0.8 * R.fused_plan_bytes("resnet50", "uniform8", 128)
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        measured = json.load(f)["resnet50_uniform8_b128"]["bytes_per_launch"]
+    model = R.fused_plan_bytes("resnet50", "uniform8", 128)
+    assert model <= measured <= 1.15 * model, (model, measured)
+
+
 def test_packing_roundtrip_and_layout():
     from hawq_amd.packing import pack_conv_weight, pack_hawq4, pack_stem_weight, unpack_hawq4
     rng = np.random.default_rng(0)
