@@ -31,6 +31,8 @@ def calibrate(model, images: torch.Tensor):
         model.forward_modules(images)
     freeze_model(model)
     model.invalidate_engine()
+    # ranges and integer buffers now come from the float parameters again, not from a quantized checkpoint
+    model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=False)
     return model
 
 
@@ -58,7 +60,9 @@ def load_quantized_checkpoint(model, ckpt, strict: bool = True):
         raise KeyError(f"not a HAWQ quantized checkpoint: missing {missing}")
     flat = {}
     for g in _QCKPT_GROUPS:
-        flat.update(ckpt[g])
+        # validate() saves the state_dict of the DataParallel-wrapped model (quant_train.py:358, 665-670): real HAWQ
+        # files carry 'module.'-prefixed keys; the TVM loader strips them the same way (hawq_utils_resnet50.py:479-485)
+        flat.update({(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt[g].items()})
     own = dict(model.named_buffers())
     own.update(dict(model.named_parameters()))
     unexpected = [k for k in flat if k not in own]
@@ -66,6 +70,11 @@ def load_quantized_checkpoint(model, ckpt, strict: bool = True):
     absent = [k for k in wanted if k not in flat]
     if strict and (unexpected or absent):
         raise KeyError(f"quantized checkpoint does not match the model: unexpected {unexpected[:3]}..., missing {absent[:3]}...")
+    if absent:
+        # an engine that trusts integer buffers must find ALL of them: running on placeholder buffers would return
+        # garbage logits without any error
+        raise KeyError(f"quantized checkpoint lacks {len(absent)} of the {len(wanted)} tensors the integer engine needs "
+                       f"(first: {absent[:3]}); nothing was loaded")
     with torch.no_grad():
         for k, v in flat.items():
             if k not in own:
@@ -117,6 +126,8 @@ def load_checkpoint(model, ckpt, freeze: bool = True):
         freeze_model(model)
         model.eval()
     model.invalidate_engine()
+    # the integer buffers are stale now (quant_train.py:309-316 drops them too): re-derive from the float parameters
+    model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=False)
     return model, missing, unexpected
 
 

@@ -67,7 +67,7 @@ class _OpList(list):
 class _Conv:
     """Device-resident parameters of one QuantBnConv2d."""
 
-    def __init__(self, mod, s_a, in_bits, dev, from_buffers):
+    def __init__(self, mod, s_a, in_bits, dev, from_buffers, in_range=None):
         if not from_buffers:
             mod.prepare(s_a)
         w_int = mod.weight_integer.detach().cpu().numpy()
@@ -85,7 +85,7 @@ class _Conv:
             self.w = torch.from_numpy(packing.pack_conv_weight(w_int, self.w_bits)).to(dev)
         self.bias = _i32(self.b_host, dev)
         # exact per-channel bound on |accumulator| -> bit length, for the requant pre-shift check
-        amax = 128 if in_bits == 8 else 15
+        amax = max(abs(int(in_range[0])), abs(int(in_range[1]))) if in_range is not None else (128 if in_bits == 8 else 15)
         bound = np.abs(np.rint(w_int.astype(np.float64))).reshape(self.cout, -1).sum(1) * amax + np.abs(self.b_host)
         self.vbits = np.array([int(b).bit_length() for b in bound], np.int64)
         if (self.vbits > 31).any():
@@ -136,6 +136,11 @@ class IntegerEngine:
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._batch = None
         self._graph = None
+        # uint16 residual plan: a forward whose un-clamped residual (quant_utils.py:456) exceeds 65535 raises the
+        # sticky device flag; the public entry points then redo that batch on a cached int32-residual twin
+        self._wide = None
+        self.overflow_fallbacks = 0
+        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._prepare_params()
 
     # ------------------------------------------------------------------ host-side preparation
@@ -157,7 +162,7 @@ class IntegerEngine:
         stem = m.stem
         if tuple(stem.conv.kernel_size) != (7, 7) or stem.conv.stride[0] != 2 or stem.conv.in_channels > 4:
             raise NotImplementedError("stem must be the 7x7/2 conv of the ImageNet ResNets")
-        sc = _Conv(stem, s_in, 8, dev, self.from_buffers)
+        sc = _Conv(stem, s_in, 8, dev, self.from_buffers, _act_range(qi.activation_bit, qi.quant_mode))
         sc.w = torch.from_numpy(packing.pack_stem_weight(sc.w_host)).to(dev)
         a0 = m.quant_act_int32
         s0 = self._scale(a0)
@@ -177,11 +182,11 @@ class IntegerEngine:
             if not units:  # the stem kernel applies the first unit's QuantAct
                 P['stem']['fast'] = P['stem']['fast'] and tables_are_fast(mq, eq, U16_VBITS)
             if d['resize']:
-                d['ident'] = _Conv(u.quant_identity_convbn, s_a, d['a_bits'], dev, self.from_buffers)
-            s_x, bits_x = s_a, d['a_bits']
+                d['ident'] = _Conv(u.quant_identity_convbn, s_a, d['a_bits'], dev, self.from_buffers, d['a_rng'])
+            s_x, bits_x, rng_x = s_a, d['a_bits'], d['a_rng']
             d['convs'] = []
             for i in range(1, u.n_body + 1):
-                c = _Conv(getattr(u, f"quant_convbn{i}"), s_x, bits_x, dev, self.from_buffers)
+                c = _Conv(getattr(u, f"quant_convbn{i}"), s_x, bits_x, dev, self.from_buffers, rng_x)
                 ent = dict(conv=c)
                 if i < u.n_body:
                     act = getattr(u, f"quant_act{i}")
@@ -193,7 +198,7 @@ class IntegerEngine:
                                k0=_no_preshift(ee))
                     if ent['fast']:
                         ent['ctab'] = _i32(packing.pack_ctab(c.b_host, mm, ee), dev)
-                    s_x, bits_x = s_n, ent['out_bits']
+                    s_x, bits_x, rng_x = s_n, ent['out_bits'], ent['rng']
                 else:
                     ent['s_last'] = s_x
                 d['convs'].append(ent)
@@ -257,6 +262,10 @@ class IntegerEngine:
                 raise NotImplementedError("4-bit activations are stored unsigned (asymmetric mode)")
             return 4
         if act.activation_bit <= 8:
+            # stored in int8 operands: an 8-bit 'asymmetric' range (0..255) would wrap, narrower ones fit
+            if _act_range(act.activation_bit, act.quant_mode)[1] > 127:
+                raise NotImplementedError("8-bit activations must be 'symmetric' (an unsigned 0..255 range does not fit "
+                                          "the int8 conv operands)")
             return 8
         raise NotImplementedError("conv inputs wider than 8 bits")
 
@@ -269,10 +278,12 @@ class IntegerEngine:
         when it was left open)."""
         if x_view is None and getattr(self, "chains_req", 1) == 0 and self.use_graph and self.autotune:
             timing = {}
-            for c in ((1, 2, 3) if N >= 48 else (1,)):
+            # small batches (what one GPU sees when 128 images are sharded over 4 / 8 ranks) launch fewer workgroups
+            # than the chip has CUs in most layers: two concurrent half-batches can still pay, three never did
+            for c in ((1, 2, 3) if N >= 48 else ((1, 2) if N >= 8 else (1,))):
                 self.chains = c
                 self._build_chains(N, H, W)
-                timing[c] = self._time_graph() if N >= 48 else 0.0
+                timing[c] = self._time_graph() if N >= 8 else 0.0
                 self._drop_graph()
             self.chains = min(timing, key=timing.get)
             self.chain_timing_ms = timing
@@ -563,6 +574,9 @@ class IntegerEngine:
                 op()
 
     def __call__(self, x):
+        """fp32 NCHW images on the GPU -> a FRESH fp32 logits tensor.  With the uint16 residual plan the sticky
+        overflow flag is read back after the forward (one stream synchronisation) and an overflowing batch is
+        transparently recomputed with int32 residuals: the reference never clamps there (quant_utils.py:456)."""
         if not x.is_cuda:
             raise RuntimeError("IntegerEngine: input must be on the MI355X (no CPU path)")
         N, Cc, H, W = x.shape
@@ -575,8 +589,31 @@ class IntegerEngine:
         with torch.cuda.stream(self.stream):
             self.x_in.copy_(x, non_blocking=True)
             self.run_resident()
+            out = self._checked_logits(lambda wide: wide(x))
         cur.wait_stream(self.stream)
-        return self.logits
+        return out
+
+    def _checked_logits(self, redo):
+        """Clone of ``self.logits`` for the forward just queued on ``self.stream`` - or, if that forward saturated a
+        uint16 residual, the logits of ``redo(int32-residual engine)``.  Called inside ``torch.cuda.stream(self.stream)``."""
+        out = self.logits.clone()
+        if self.res_bits != 16:
+            return out
+        self._flag_host.copy_(self.flags, non_blocking=True)
+        self.stream.synchronize()
+        if not (int(self._flag_host.item()) & 1):
+            return out
+        self.flags.zero_()
+        self.overflow_fallbacks += 1
+        self.stream.synchronize()
+        return redo(self.wide_engine())
+
+    def wide_engine(self):
+        """The int32-residual twin of this plan (exact general kernels on the residual path; built on first use)."""
+        if self._wide is None:
+            self._wide = IntegerEngine(self.model, residual_bits=32, from_buffers=self.from_buffers, use_graph=False,
+                                       fast=self.fast, autotune=False, chains=1)
+        return self._wide
 
     def run_resident(self, u8: bool = False):
         """One forward over ``self.x_in`` (or, ``u8``, over ``self.x_u8``) already resident, on ``self.stream``."""
@@ -648,8 +685,9 @@ class IntegerEngine:
                 self._lut_key = key
             self.x_u8.copy_(x_u8, non_blocking=True)
             self.run_resident(u8=True)
+            out = self._checked_logits(lambda wide: wide.forward_uint8(x_u8, mean, std))
         cur.wait_stream(self.stream)
-        return self.logits
+        return out
 
     def profile_ops(self, repeats: int = 5):
         """Per-launch durations (ms, median of ``repeats``) measured with HIP events around each
@@ -677,7 +715,9 @@ class IntegerEngine:
         return [(n, sorted(v)[len(v) // 2]) for n, v in zip(self._ops.names, samples)]
 
     def overflowed(self) -> bool:
-        """True if a uint16 residual saturated since construction (then rebuild with residual_bits=32)."""
+        """True if a uint16 residual saturated in a ``run_resident`` forward that nobody has handled yet.  ``__call__`` /
+        ``forward_uint8`` check and clear the flag themselves (``overflow_fallbacks`` counts the batches they redid with
+        int32 residuals); callers of the raw ``run_resident`` (bench.py) read it here."""
         return bool(self.flags.item() & 1)
 
     def accumulators(self, name):

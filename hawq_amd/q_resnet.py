@@ -100,6 +100,8 @@ class _QResNet(nn.Module):
         self.quant_output.set_param(getattr(model, 'output'))
         self.fused = True          # use the integer plan when frozen + eval + CUDA
         self._engine = None
+        # new parameters / ranges make a cached plan (packed weights, tables, hipGraph) stale
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_engine())
 
     # -- structure helpers -------------------------------------------------------------------
     @property

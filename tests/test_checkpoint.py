@@ -47,6 +47,39 @@ def test_checkpoint_structure_round_trip(tmp_path):
         load_quantized_checkpoint(b, {"weight_integer": {}})
 
 
+def test_dataparallel_prefixed_checkpoint_and_partial_files(tmp_path):
+    """validate() saves the state_dict of the DataParallel-wrapped network (quant_train.py:358, 665-670): keys carry a
+    'module.' prefix.  They must load like un-prefixed ones; a file that lacks tensors the integer engine needs is
+    refused even with strict=False (it must never run on placeholder buffers)."""
+    from hawq_amd.api import build_quantized_resnet, load_checkpoint, load_quantized_checkpoint
+    a = build_quantized_resnet("resnet18", "uniform8", seed=1)
+    _random_fill(a, 4)
+    sd = a.state_dict()
+    ck = {g: {"module." + k: v.clone() for k, v in sd.items() if g in k} for g in GROUPS}
+    b = build_quantized_resnet("resnet18", "uniform8", seed=2)
+    load_quantized_checkpoint(b, ck, strict=True)
+    assert b.engine_defaults == {"from_buffers": True}
+    for k, v in sd.items():
+        if any(g in k for g in GROUPS):
+            assert torch.equal(b.state_dict()[k], v), k
+    # drop one conv's integer weights: refused, strict or not
+    victim = next(k for k in ck["weight_integer"] if "stage2" in k)
+    del ck["weight_integer"][victim]
+    for strict in (True, False):
+        c = build_quantized_resnet("resnet18", "uniform8", seed=2)
+        with pytest.raises(KeyError):
+            load_quantized_checkpoint(c, ck, strict=strict)
+        assert not getattr(c, "engine_defaults", {}).get("from_buffers", False)
+    # new float parameters make the integer buffers stale: a later float load stops trusting them
+    fl = {"state_dict": {"module." + k: v for k, v in a.state_dict().items()}}
+    load_checkpoint(b, fl)
+    assert b.engine_defaults == {"from_buffers": False}
+    # ... and a raw load_state_dict drops a cached plan
+    b._engine = object()
+    b.load_state_dict(a.state_dict(), strict=False)
+    assert b._engine is None
+
+
 @pytest.mark.reference
 def test_loads_the_file_the_live_reference_writes(tmp_path):
     """The reference's own frozen ResNet18 -> its torch.save(...) of quant_train.py:665-670 -> our loader (strict):

@@ -5,6 +5,8 @@ import os
 import socket
 
 import pytest
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.multiprocessing as mp
 
@@ -58,3 +60,35 @@ def test_shard_bounds_cover_batch():
             spans = [shard_bounds(batch, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == batch
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_bench_strong_scaling_shards_line_up_with_the_golden_logits():
+    """bench.py --scaling strong: rank r evaluates images shard_bounds(128, r, N) of ONE batch and checks its logits
+    against the same rows of the oracle fixture; the gathered result is the fixture itself."""
+    import numpy as np
+    import bench
+    from hawq_amd.dist import shard_bounds
+    from tests import helpers as H
+    fx = H.load("b128_resnet50_uniform8.npz")
+    full = torch.from_numpy(fx["logits"])
+    for world in (1, 2, 4, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_bounds(128, r, world)
+            assert hi - lo == 128 // world
+            assert bench.golden_parity("resnet50", "uniform8", 128, 1, full[lo:hi], lo) is True
+            parts.append(full[lo:hi])
+        assert torch.equal(torch.cat(parts), full)
+    wrong = full.clone()
+    wrong[5, 7] += 1
+    assert bench.golden_parity("resnet50", "uniform8", 128, 1, wrong) is False
+    assert bench.golden_parity("resnet50", "uniform8", 64, 1, full[:64]) is None   # no fixture for other batches
+
+
+@pytest.mark.gpu
+def test_rccl_gather_executes_on_the_gpu_at_world_size_one():
+    """The collective of the multi-GPU path (one all_gather of the logits over RCCL) executed for real, in a world of
+    one rank: hawq_amd.dist.gather_logits short-circuits there, so call the collective directly as bench.py does."""
+    import bench
+    x = torch.randn(128, 1000, device="cuda")
+    assert bench.rccl_world1_selfcheck(torch.device("cuda", 0), x) is True

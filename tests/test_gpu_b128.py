@@ -1,0 +1,94 @@
+"""Parity AT THE BENCHMARKED CONFIGURATION (BASELINE.json configs[1..4]): the engine is built by bench.py's own
+`setup_workload` - hipGraph, per-layer autotuned tiles, automatically chosen concurrent sub-batches - at batch 128 and
+all 128 x 1000 logits + top-1 must equal the CPU oracle's (tests/golden/b128_*.npz, written by
+tests/golden/make_b128.py from oracle.forward_int in slices of 16 images; one slice is recomputed live here so the
+fixture is tied to the oracle on this box too).  Reference lines: quant_train.py:625-674 (validate), q_resnet.py:53-135."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [("resnet18", "uniform8"), ("resnet50", "uniform8"), ("resnet50", "uniform4"), ("resnet50", "bops_0.5")]
+
+
+@pytest.mark.parametrize("arch,scheme", CONFIGS)
+def test_benchmarked_configuration_is_bit_exact_at_batch_128(arch, scheme):
+    import bench
+    from oracle import oracle
+
+    fx = H.load(f"b128_{arch}_{scheme}.npz")
+    dev = torch.device("cuda", 0)
+    model, eng, x = bench.setup_workload(arch, scheme, 128, dev, seed=int(fx["seed"]))
+    assert H.sha(x.cpu().numpy()) == str(fx["input_sha"])
+    assert eng.use_graph and eng.autotune and eng.chains in (1, 2, 3) and eng.res_bits == 16
+    # the shipped path: replay of the captured graph on the resident batch, as bench.py's timed loop does
+    with torch.cuda.stream(eng.stream):
+        eng.run_resident()
+        eng.run_resident()
+    torch.cuda.synchronize()
+    y = eng.logits.cpu().numpy()
+    assert not eng.overflowed() and int(fx["residual_max"]) < 65536
+    assert np.array_equal(y, fx["logits"]), f"{int((y != fx['logits']).any(1).sum())} of 128 images differ"
+    assert np.array_equal(y.argmax(1), fx["top1"])
+    # the public entry point (flag check + fresh tensor) agrees and needed no int32 fallback
+    y2 = eng(x)
+    assert y2.data_ptr() != eng.logits.data_ptr() and np.array_equal(y2.cpu().numpy(), y) and eng.overflow_fallbacks == 0
+    # one slice recomputed by the oracle on this box (images of the LAST sub-batch)
+    st = oracle.extract_float_state(model)
+    s = int(fx["slice"])
+    ref, tr = oracle.forward_int(st, x[128 - s:].cpu().numpy())
+    assert np.array_equal(ref, fx["logits"][128 - s:])
+    names = [str(n) for n in fx["residual_names"]]
+    assert [H.sha(tr[n].astype(np.int32)) for n in names] == [str(v) for v in fx["residual_sha"][-1]]
+    print(f"{arch} {scheme}: chains {eng.chains}, tiles {'.'.join(str(t) for t in eng.tile_choice.values())}")
+
+
+@pytest.mark.parametrize("batch", [16, 32, 64])
+def test_per_rank_batches_of_the_strong_scaling_shard_are_bit_exact(batch):
+    """What each GPU runs when one batch of 128 is sharded over 8 / 4 / 2 ranks: the first `batch` images
+    of the benchmarked ResNet50-W8A8 workload, same engine configuration as bench.py."""
+    import bench
+    fx = H.load("b128_resnet50_uniform8.npz")
+    dev = torch.device("cuda", 0)
+    model, eng, x = bench.setup_workload("resnet50", "uniform8", 128, dev, seed=int(fx["seed"]), shard=(0, batch))
+    with torch.cuda.stream(eng.stream):
+        eng.run_resident()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.logits.cpu().numpy(), fx["logits"][:batch]) and not eng.overflowed()
+
+
+@pytest.mark.parametrize("arch,scheme", [("resnet18", "uniform8"), ("resnet50", "uniform8")])
+def test_uint16_residual_overflow_heals_itself(arch, scheme):
+    """Inputs far outside the calibration range push the un-clamped residual sum (quant_utils.py:416-456: no clamp)
+    beyond 65535.  model(x) must still equal the oracle without the caller touching overflowed(): the engine redoes
+    the batch with int32 residuals; later in-range batches go back to the fast plan."""
+    from hawq_amd.api import calibrate
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import oracle
+    model = H.build_model(arch, scheme)
+    calibrate(model, synthetic_images(2, 0).cuda())
+    st = oracle.extract_float_state(model)
+    x_big = synthetic_images(3, seed=3) * 6
+    ref_big, tr = oracle.forward_int(st, x_big.numpy())
+    assert max(int(v.max()) for k, v in tr.items() if k.endswith("quant_act_int32.q")) > 65535
+    x_ok = synthetic_images(3, seed=4)
+    ref_ok, _ = oracle.forward_int(st, x_ok.numpy())
+    y_ok = model(x_ok.cuda())
+    eng = model._engine
+    assert np.array_equal(y_ok.cpu().numpy(), ref_ok) and eng.overflow_fallbacks == 0
+    y_big = model(x_big.cuda())
+    assert np.array_equal(y_big.cpu().numpy(), ref_big)
+    assert eng.overflow_fallbacks == 1 and not eng.overflowed()
+    assert np.array_equal(model(x_ok.cuda()).cpu().numpy(), ref_ok) and eng.overflow_fallbacks == 1
+    assert np.array_equal(y_ok.cpu().numpy(), ref_ok)  # earlier results are not aliased by later forwards
+    # uint8 image path: every pixel at the extremes of the table
+    g = torch.Generator().manual_seed(0)
+    xu8 = (torch.randint(0, 2, (3, 224, 224, 3), generator=g) * 255).to(torch.uint8)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    t = xu8.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    t = t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))
+    ref_u8, _ = oracle.forward_int(st, t.numpy())
+    assert np.array_equal(eng.forward_uint8(xu8.cuda(), mean, std).cpu().numpy(), ref_u8)

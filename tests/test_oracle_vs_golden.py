@@ -256,3 +256,25 @@ def test_fakequant_port_matches_reference(arch, scheme):
     y = fakequant_port.forward(st, synthetic_images(2, 0)).numpy()
     assert np.array_equal(y.argmax(1), fx["top1"])
     assert np.array_equal(y, fx["logits"])
+
+
+def test_b128_fixture_is_what_the_oracle_computes():
+    """tests/golden/b128_*.npz (the benchmarked workloads at batch 128, consumed by the GPU parity tests and by
+    bench.py) were written by tests/golden/make_b128.py from this oracle: recompute one 16-image slice of the
+    ResNet18 fixture and its per-unit residual digests."""
+    import hashlib
+    from hawq_amd.api import build_quantized_resnet
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import oracle
+    fx = H.load("b128_resnet18_uniform8.npz")
+    model = build_quantized_resnet("resnet18", "uniform8", seed=0)
+    st = oracle.extract_float_state(model)
+    oracle.forward_int(st, synthetic_images(int(fx["calib"]), seed=0).numpy(), calibrate=True)
+    x = synthetic_images(128, seed=int(fx["seed"])).numpy()
+    assert hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() == str(fx["input_sha"])
+    s = int(fx["slice"])
+    y, tr = oracle.forward_int(st, x[3 * s:4 * s])
+    assert np.array_equal(y, fx["logits"][3 * s:4 * s])
+    assert np.array_equal(fx["logits"].argmax(1), fx["top1"])
+    for n, want in zip(fx["residual_names"], fx["residual_sha"][3]):
+        assert hashlib.sha256(np.ascontiguousarray(tr[str(n)].astype(np.int32)).tobytes()).hexdigest() == str(want), n
