@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ("out_q", vp), ("out_bits", i32), ("q_lo", i32), ("q_hi", i32), ("mq", i32), ("eq", i32),
         ("out_acc", vp), ("out_f32", vp), ("fscale", vp), ("ldo", i32), ("n_valid", i32),
         ("flags", vp), ("tile", i32), ("ctab", vp), ("ctab_id", vp), ("fast_tables", i32),
+        ("in_planar", i32), ("out_planar", i32),
     ]
 
 
@@ -44,6 +45,7 @@ SIGNATURES = {
     "hawq_conv2d": [C.POINTER(ConvArgs), vp],
     "hawq_conv2d_num_tiles": [],
     "hawq_conv2d_num_band_tiles": [],
+    "hawq_conv2d_band_tile": [C.POINTER(ConvArgs)],
     "hawq_quantize_input": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "hawq_stem_conv7": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_stem_fused": [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32,
@@ -94,7 +96,7 @@ def load():
         fn.restype = C.c_int
     lib.hawq_last_error.restype = C.c_char_p
     lib.hawq_last_error.argtypes = []
-    if lib.hawq_abi_version() != 1:
+    if lib.hawq_abi_version() != 2:
         raise HawqLibraryError("libhawq_mi355.so ABI version mismatch")
     _lib = lib
     return lib

@@ -47,6 +47,7 @@ struct ConvP {
     const int32_t *ctab, *ctab_id;
     int k0;   // fast path requant mode (dyadic_mode): 0 tie-free, 1 tie-free + every pre-shift 0, 2 exact tie handling
     int ring_bytes;  // LDS bytes of the operand ring actually allocated (fewer stages when the K loop is shorter than the ring)
+    int in_planar, out_planar;  // activation layout of in / out_q: 0 = NHWC rows, 1 = channel-group planes (hawq_mi355.h)
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
@@ -748,7 +749,36 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
             }
         }
     }
-    if (!RES || p.out_q) {
+    if ((!RES || p.out_q) && p.out_planar) {
+        // channel-group planes [C / G][M][16 B] (G = 16 int8 / 32 hawq4 channels): what the 3x3 band kernel's LDS-DMA
+        // fill wants - 64 consecutive pixels of one plane are one contiguous KiB (tools/ubench/ingest_shape.hip:
+        // 16-byte segments a pixel row apart reach 16 GB/s per CU, contiguous ones 57-87).  Pixel index fastest
+        // across lanes: 16-B stores of consecutive pixels are contiguous in a plane.
+        if (p.out_bits == 8) {
+#pragma unroll
+            for (int i = 0; i < (C::BM * S::QCPR + C::NT - 1) / C::NT; ++i) {
+                const int idx = t + C::NT * i;
+                const int ch = idx / C::BM, row = idx % C::BM;
+                if (idx < C::BM * S::QCPR && m0 + row < p.M) {
+                    char *dst = (char *)p.out_q + ((size_t)((c0 >> 4) + ch) * p.M + (m0 + row)) * 16;
+                    *reinterpret_cast<v4i *>(dst) = *reinterpret_cast<const v4i *>(q_tile + (row * S::QCPR + (ch ^ S::qsw(row))) * 16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (C::BM * (S::QCPR / 2) + C::NT - 1) / C::NT; ++i) {
+                const int idx = t + C::NT * i;
+                const int u = idx / C::BM, row = idx % C::BM;
+                if (idx < C::BM * (S::QCPR / 2) && m0 + row < p.M) {
+                    const v2i a = *reinterpret_cast<const v2i *>(q_tile + (row * S::QCPR + ((2 * u) ^ S::qsw(row))) * 16);
+                    const v2i b = *reinterpret_cast<const v2i *>(q_tile + (row * S::QCPR + ((2 * u + 1) ^ S::qsw(row))) * 16);
+                    const v4i w = {a.x, a.y, b.x, b.y};
+                    char *dst = (char *)p.out_q + ((size_t)((c0 >> 5) + u) * p.M + (m0 + row)) * 16;
+                    *reinterpret_cast<v4i *>(dst) = w;
+                }
+            }
+        }
+    } else if (!RES || p.out_q) {
 #pragma unroll
         for (int i = 0; i < (C::BM * S::QCPR + C::NT - 1) / C::NT; ++i) {
             const int idx = t + C::NT * i;
@@ -881,7 +911,7 @@ struct BandCfg {
     static constexpr int RPI = RG / ND, WPI = 3 * RPI;        // W row groups / pieces per issuing wave per step
     static constexpr int WTAP = BN * 64, WSTAGE = 3 * WTAP;
     static constexpr int LDS_BYTES = BSTAGES * BAND_BYTES + WS * WSTAGE;
-    static_assert(RG % ND == 0 && (BAND_PX / 16) % ND == 0 && PT >= 1 && CT >= 1, "tile shape");
+    static_assert(RG % ND == 0 && (BAND_PX / 16) % ND == 0 && PT >= 1 && CT >= 1 && WS >= 3 && WS <= 5, "tile shape");
     static_assert(BM * BN * 2 <= LDS_BYTES, "epilogue staging aliases the rings");
 };
 
@@ -917,6 +947,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
     const int rowb = NIB ? p.Cin >> 1 : p.Cin;  // bytes per pixel / per filter tap of one output channel
     const int cchunks = rowb >> 6;
     const int nsteps = 3 * cchunks;             // step s = cc * 3 + kh
+    const size_t slice_stride = p.in_planar ? (size_t)p.M * 64 : 64;  // bytes from one 64-byte channel slice to the next
 
     // ------------------------------------------------------------------ LDS-DMA side (issuing waves)
     const char *bsrc[C::BPI];   // band piece j = i * ND + dw fills 64 pixels of plane (j & 3)
@@ -930,7 +961,11 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
             const int br = bpx / Wb, bc = bpx - br * Wb;
             const int G = G0 + br, x = bc - 1;
             const bool v = (unsigned)G < (unsigned)rows_total && (unsigned)x < (unsigned)Wo && bpx < C::BAND_PX - 4;
-            bsrc[i] = v ? (const char *)p.in + ((size_t)G * Wo + x) * rowb + ((j & 3) << 4) : nullptr;
+            // NHWC: 16 bytes of a pixel row (64 lanes = 64 segments a row apart: slow, see ingest_shape.hip); planar:
+            // plane (cc * 4 + (j & 3)) is [M][16 B], the lanes of a band row read consecutive 16-byte units
+            bsrc[i] = !v ? nullptr
+                      : p.in_planar ? (const char *)p.in + ((size_t)(j & 3) * p.M + (size_t)G * Wo + x) * 16
+                                    : (const char *)p.in + ((size_t)G * Wo + x) * rowb + ((j & 3) << 4);
         }
 #pragma unroll
         for (int r = 0; r < C::RPI; ++r) {
@@ -943,7 +978,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < C::BPI; ++i) {
             const int j = i * C::ND + dw;
-            const char *src = bsrc[i] ? bsrc[i] + (cc << 6) : zero;
+            const char *src = bsrc[i] ? bsrc[i] + (size_t)cc * slice_stride : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dst + (j & 3) * C::PLANE + (j >> 2) * 1024), 16, 0, 0);
         }
@@ -965,8 +1000,9 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         if (s2 < nsteps) issue_w(s2, s2 / 3, s2 % 3);
     };
     // Before barrier #(s+1) the issuing waves must have seen W(s+2) land.  With WS == 3 that is the W issued in this
-    // very step (everything must have landed); with WS == 4 it was issued one step earlier, and this step's band
-    // prefetch and W(s+3) - younger in program order - may stay in flight.
+    // very step (everything must have landed).  With WS >= 4 it was issued WS - 3 steps earlier: everything issued in
+    // this step and in the WS - 4 steps before it - younger in program order, and LDS-DMA completes in order - may stay
+    // in flight (a band prefetch happens in steps with kh == 0 only, so at most one of two consecutive steps has one).
     auto wait_step = [&](int s, int cc, int kh) {
         if (C::WS <= 3) {
             wait_vmcnt<0>();
@@ -974,10 +1010,23 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         }
         const bool band_now = C::BSTAGES > 1 && kh == 0 && cc + 1 < cchunks;
         const bool w_now = s + C::WS - 1 < nsteps;
-        if (band_now) {
-            if (w_now) wait_vmcnt<C::BPI + C::WPI>(); else wait_vmcnt<C::BPI>();
+        if (C::WS == 4) {
+            if (band_now) {
+                if (w_now) wait_vmcnt<C::BPI + C::WPI>(); else wait_vmcnt<C::BPI>();
+            } else {
+                if (w_now) wait_vmcnt<C::WPI>(); else wait_vmcnt<0>();
+            }
+            return;
+        }
+        // WS == 5: this step's and the previous step's issues
+        const int khp = kh == 0 ? 2 : kh - 1, ccp = kh == 0 ? cc - 1 : cc;
+        const bool band_prev = C::BSTAGES > 1 && s >= 1 && khp == 0 && ccp + 1 < cchunks;
+        const bool w_prev = s >= 1 && s - 1 + C::WS - 1 < nsteps;
+        const int nw = (w_now ? 1 : 0) + (w_prev ? 1 : 0);
+        if (band_now || band_prev) {
+            if (nw == 2) wait_vmcnt<C::BPI + 2 * C::WPI>(); else if (nw == 1) wait_vmcnt<C::BPI + C::WPI>(); else wait_vmcnt<C::BPI>();
         } else {
-            if (w_now) wait_vmcnt<C::WPI>(); else wait_vmcnt<0>();
+            if (nw == 2) wait_vmcnt<2 * C::WPI>(); else if (nw == 1) wait_vmcnt<C::WPI>(); else wait_vmcnt<0>();
         }
     };
 
@@ -1154,7 +1203,30 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
 using B0 = BandCfg<256, 64, 4, 1, 512, 1, 2, 0>;    // Cin == Cout == 64 (stage 1): 4 waves x (64 px x 64 ch), 2 workgroups per CU
 using B1 = BandCfg<256, 128, 4, 2, 512, 2, 1, 8>;   // 8 MFMA waves x (64 px x 64 ch) + 8 producer waves (LDS-DMA ingest scales with the issuing waves)
 using B2 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8, 4>;   // 8 MFMA waves x (64 px x 32 ch) + 8 producers: twice the workgroups for 14x14 / 7x7
-constexpr int NUM_BAND_TILES = 3;
+using B3 = BandCfg<256, 128, 4, 2, 384, 2, 1, 8, 4>;   // B1 with a 384-pixel band (14x14 / 7x7 maps): room for a 4-stage W ring
+using B4 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8, 5>;   // B2 with a 5-stage W ring (W issued 4 filter rows ahead)
+constexpr int NUM_BAND_TILES = 5;
+
+typedef void (*KernelFn)(const ConvP);
+struct BandInfo { KernelFn fn[2][2][2]; int bm, bn, band_px, bstages, lds, nt; };  // fn[hawq4][exact-tie][residual]
+#define BAND_FN(B, N, T) {conv3x3_band_kernel<B, N, T, HAWQ_EPI_REQUANT>, conv3x3_band_kernel<B, N, T, HAWQ_EPI_RESIDUAL>}
+#define BAND_ENTRY(B) {{{BAND_FN(B, false, false), BAND_FN(B, false, true)}, {BAND_FN(B, true, false), BAND_FN(B, true, true)}}, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
+const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2), BAND_ENTRY(B3), BAND_ENTRY(B4)};
+// tile ids tried, in this order, when the caller leaves the choice open for a layer that needs a band kernel
+const int kBandPreference[NUM_BAND_TILES] = {0, 3, 1, 2, 4};
+
+// Does band tile `bi` take this layer?  (3x3 / stride 1 / pad 1, single branch, fast-contract tables, int8 or hawq4
+// operands, REQUANT or 16-bit RESIDUAL epilogue, the band of a pixel tile fits the LDS stage)
+bool band_applies(const BandInfo &bi, const hawq_conv_args *a) {
+    const int wo = a->W, band_rows = (bi.bm + wo - 1) / wo + 1 + 2;
+    const bool nib = a->in_bits == 4 && a->w_bits == 4;
+    const bool res = a->epilogue == HAWQ_EPI_RESIDUAL;
+    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q) ||
+                        (res && a->res_in && a->res_in_bits == 16 && (!a->res_out || a->res_out_bits == 16));
+    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && epi_ok &&
+           ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) && a->Cout % bi.bn == 0 &&
+           band_rows * (wo + 2) <= bi.band_px - 4 && (bi.bstages > 1 || (a->Cin >> (nib ? 7 : 6)) == 1);
+}
 
 using T0 = Cfg<128, 128, 2, 2, 3>;
 using T1 = Cfg<256, 64, 4, 1, 3>;
@@ -1178,7 +1250,6 @@ using T12 = Cfg<128, 64, 2, 2, 2, 1, 3>;
 using T13 = Cfg<128, 128, 2, 4, 2, 1, 2>;
 constexpr int NUM_TILES = 14;
 
-typedef void (*KernelFn)(const ConvP);
 // single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
 // dual-branch (RESIDUAL + identity conv): {run-time, 88/88, 44/44, 88/44, 44/88}
 struct TileInfo {
@@ -1245,6 +1316,13 @@ int pick_tile(int M, int Cout, bool dual) {
 
 extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES; }  // the 3x3 band kernels are the last ids
 extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES; }
+
+extern "C" int hawq_conv2d_band_tile(const hawq_conv_args *a) {
+    if (!a || a->W <= 0 || a->H <= 0 || a->Cin <= 0 || a->Cout <= 0) return 0;
+    for (int k = 0; k < NUM_BAND_TILES; ++k)
+        if (band_applies(kBand[kBandPreference[k]], a)) return NUM_TILES + kBandPreference[k] + 1;
+    return 0;
+}
 
 extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     HAWQ_REQUIRE(a != nullptr, "hawq_conv2d: null args");
@@ -1351,25 +1429,24 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         default:
             HAWQ_REQUIRE(false, "hawq_conv2d: unknown epilogue %d", a->epilogue);
     }
+    p.in_planar = a->in_planar, p.out_planar = a->out_planar;
+    HAWQ_REQUIRE((a->in_planar | a->out_planar | 1) == 1, "hawq_conv2d: in_planar / out_planar must be 0 or 1");
+    HAWQ_REQUIRE(!a->out_planar || (fast && a->out_q && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL) &&
+                                    !(a->epilogue == HAWQ_EPI_RESIDUAL && a->res_out && a->res_out_bits == 32)),
+                 "hawq_conv2d: out_planar needs the fast-contract REQUANT / RESIDUAL epilogue");
     int tile = a->tile > 0 ? a->tile - 1 : pick_tile(p.M, p.Cout, dual);
+    if (a->tile == 0 && a->in_planar) {  // only the band kernels read planar activations: first one that takes the layer
+        tile = -1;
+        for (int k = 0; k < NUM_BAND_TILES && tile < 0; ++k)
+            if (band_applies(kBand[kBandPreference[k]], a)) tile = NUM_TILES + kBandPreference[k];
+        HAWQ_REQUIRE(tile >= 0, "hawq_conv2d: in_planar input but no 3x3 band kernel takes this layer");
+    }
     if (tile >= NUM_TILES && tile < NUM_TILES + NUM_BAND_TILES) {
-        // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 REQUANT layers only
-        struct BandInfo { KernelFn fn[2][2][2]; int bm, bn, band_px, bstages, lds, nt; };  // fn[hawq4][exact-tie][residual]
-#define BAND_FN(B, N, T) {conv3x3_band_kernel<B, N, T, HAWQ_EPI_REQUANT>, conv3x3_band_kernel<B, N, T, HAWQ_EPI_RESIDUAL>}
-#define BAND_ENTRY(B) {{{BAND_FN(B, false, false), BAND_FN(B, false, true)}, {BAND_FN(B, true, false), BAND_FN(B, true, true)}}, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
-        static const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2)};
+        // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 / hawq4 layers only
         const BandInfo &bi = kBand[tile - NUM_TILES];
-        const int bn = bi.bn;
-        const int wo = p.Wo, band_rows = (bi.bm + wo - 1) / wo + 1 + 2;
         const bool nib = a->in_bits == 4 && a->w_bits == 4;
         const bool res = a->epilogue == HAWQ_EPI_RESIDUAL;
-        const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q) ||
-                            (res && a->res_in && a->res_in_bits == 16 && (!a->res_out || a->res_out_bits == 16));
-        const bool ok = a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && !dual && fast && epi_ok &&
-                        ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) &&
-                        p.Cout % bn == 0 && band_rows * (wo + 2) <= bi.band_px - 4 &&
-                        (bi.bstages > 1 || (a->Cin >> (nib ? 7 : 6)) == 1);
-        HAWQ_REQUIRE(ok, "hawq_conv2d: tile %d (3x3 band kernel) does not apply to this layer", a->tile);
+        HAWQ_REQUIRE(band_applies(bi, a), "hawq_conv2d: tile %d (3x3 band kernel) does not apply to this layer", a->tile);
         static const bool band_attrs = [] {
             bool good = true;
             for (const BandInfo &b : kBand)
@@ -1378,7 +1455,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             return good;
         }();
         HAWQ_REQUIRE(band_attrs, "hawq_conv2d: hipFuncSetAttribute failed for the band kernels");
-        const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bn);
+        const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bi.bn);
         hipLaunchKernelGGL(bi.fn[nib ? 1 : 0][p.k0 == 2 ? 1 : 0][res ? 1 : 0], dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
         HAWQ_CHECK_HIP(hipGetLastError());
         if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
@@ -1386,10 +1463,11 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             (void)hipStreamSynchronize((hipStream_t)stream);
             (void)hipMemcpy(hbuf, p.dbgbuf, sizeof(hbuf), hipMemcpyDeviceToHost);
             fprintf(stderr, "[band bm=%d bn=%d M=%d Cin=%d Cout=%d] steps %lld: prologue %lld | K loop %lld | epilogue %lld cycles (wave 0 of workgroup 8, s_memtime)\n",
-                    bi.bm, bn, p.M, p.Cin, p.Cout, hbuf[3], hbuf[0], hbuf[1], hbuf[2]);
+                    bi.bm, bi.bn, p.M, p.Cin, p.Cout, hbuf[3], hbuf[0], hbuf[1], hbuf[2]);
         }
         return 0;
     }
+    HAWQ_REQUIRE(!a->in_planar, "hawq_conv2d: in_planar activations are read by the 3x3 band kernels only (tile %d is not one)", a->tile);
     HAWQ_REQUIRE(tile >= 0 && tile < NUM_TILES, "hawq_conv2d: bad tile id %d", a->tile);
     if (p.Cout % kTiles[tile].BN != 0) tile = 2;
     if (kTiles[tile].ksub > 1) {  // K = 128 per barrier: int8 x int8 async pipeline with even chunk counts only

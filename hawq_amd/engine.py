@@ -105,7 +105,7 @@ class IntegerEngine:
         if _parent is not None:  # a chain of a multi-chain engine: shares parameters, owns stream + buffers
             self.__dict__.update({k: v for k, v in _parent.__dict__.items()
                                   if k in ("model", "dev", "res_bits", "from_buffers", "keep_acc", "fast", "autotune",
-                                           "flags", "P")})
+                                           "flags", "P", "planar")})
             self.use_graph, self.chains, self.subs = False, 1, []
             self.stream = torch.cuda.Stream(device=self.dev)
             self.tile_choice = {}
@@ -124,6 +124,8 @@ class IntegerEngine:
         self.keep_acc = keep_accumulators
         self.fast = fast  # False forces the exact general kernels everywhere (reference for tests)
         self.autotune = autotune  # pick each conv launch's tile configuration by timing it once per batch shape
+        # conv1 -> 3x3 conv2 tensors as channel-group planes (include/hawq_mi355.h: in_planar / out_planar)
+        self.planar = not keep_accumulators and not os.environ.get("HAWQ_NO_PLANAR")
         self.tile_choice = {}
         # chains > 1: the batch is split into independent sub-batches whose launch chains run on separate
         # streams inside ONE hipGraph, so that one chain's kernel tails / prologues / epilogues overlap the
@@ -270,6 +272,23 @@ class IntegerEngine:
         raise NotImplementedError("conv inputs wider than 8 bits")
 
     # ------------------------------------------------------------------ launch list
+    def _band_takes(self, ent, N, h, w, in_bits, is_last, u) -> bool:
+        """Would a 3x3 band kernel take the conv `ent` fed with an [N,h,w] map of `in_bits`-bit activations?  Asked
+        of the library itself (hawq_conv2d_band_tile) with the launch's geometry, widths and epilogue class."""
+        c = ent['conv']
+        if not ent.get('fast', False) or self.res_bits != 16 or not self.fast:
+            return False
+        q = _lib.ConvArgs()
+        q.N, q.H, q.W, q.Cin, q.Cout, q.KH, q.KW, q.stride, q.pad = N, h, w, c.cin, c.cout, c.kh, c.kw, c.stride, c.pad
+        q.in_bits, q.w_bits, q.fast_tables = in_bits, c.w_bits, 1
+        if is_last:  # RESIDUAL epilogue: single-branch uint16 residual only
+            if u['resize']:
+                return False
+            q.epilogue, q.res_in, q.res_in_bits, q.res_out_bits = _lib.EPI_RESIDUAL, 1, 16, 16
+        else:
+            q.epilogue, q.out_q = _lib.EPI_REQUANT, 1
+        return _lib.load().hawq_conv2d_band_tile(C.byref(q)) != 0
+
     def _alloc(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.dev)
 
@@ -384,7 +403,7 @@ class IntegerEngine:
         res_bits_in = 16
         for ui, u in enumerate(units):
             nxt = units[ui + 1] if ui + 1 < len(units) else None
-            x_in, x_bits, hin, win = qa, u['a_bits'], h, w
+            x_in, x_bits, hin, win, x_planar = qa, u['a_bits'], h, w, False
             for ci, ent in enumerate(u['convs']):
                 c = ent['conv']
                 ho, wo = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
@@ -409,6 +428,7 @@ class IntegerEngine:
                 self.n_fast += int(a.fast_tables != 0)
                 self.n_conv += 1
                 a.tile = int(os.environ.get("HAWQ_TILE_RES" if ci == len(u['convs']) - 1 else "HAWQ_TILE_REQ", "0"))
+                a.in_planar = int(x_planar)
                 tap_name = f"{u['name']}.quant_convbn{ci + 1}"
                 if ci < len(u['convs']) - 1:
                     out = self._alloc(N * ho * wo * c.cout * ent['out_bits'] // 8, torch.uint8)
@@ -416,6 +436,11 @@ class IntegerEngine:
                     a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), ent['out_bits'], ent['rng'][0], ent['rng'][1]
                     keep.append(out)
                     x_next, xb_next = out, ent['out_bits']
+                    # the only reader of `out` is the next conv of this unit: if that is a 3x3 layer a band kernel
+                    # takes, write channel-group planes (what the band kernel's LDS-DMA fill reads at full rate)
+                    planar_next = bool(a.fast_tables) and self.planar and self._band_takes(u['convs'][ci + 1], N, ho, wo, xb_next,
+                                                                                            ci + 1 == len(u['convs']) - 1, u)
+                    a.out_planar = int(planar_next)
                 else:
                     a.epilogue = _lib.EPI_RESIDUAL
                     if u['resize']:
@@ -448,7 +473,7 @@ class IntegerEngine:
                 ops.next_name = tap_name + ("+identity" if (a.in2 is not None) else "")
                 ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
                 if ci < len(u['convs']) - 1:
-                    x_in, x_bits, hin, win = x_next, xb_next, ho, wo
+                    x_in, x_bits, hin, win, x_planar = x_next, xb_next, ho, wo, planar_next
             res, qa, h, w = new_res, new_qa, ho, wo
             res_bits_in = self.res_bits
         cl = units[-1]['convs'][-1]['conv'].cout

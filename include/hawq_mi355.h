@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HAWQ_ABI_VERSION 1
+#define HAWQ_ABI_VERSION 2
 
 const char *hawq_last_error(void);
 int hawq_abi_version(void);
@@ -111,6 +111,11 @@ typedef struct hawq_conv_args {
                              Bit 2 (value 5): the tie-freedom proof FAILED for some entry; the kernel
                              then applies the exact round-half-even tie correction to every requant
                              of the call (e in [33,62] and |value << k| < 2^31 still required).     */
+    int32_t in_planar;    /* layout of `in`: 0 = NHWC pixel rows [M][Cin*bits/8];  1 = channel-group planes
+                             [Cin/G][M][16 B] with G = 16 (int8) / 32 (hawq4) channels per 16-byte unit.  Planes
+                             are what the 3x3 band kernels' LDS-DMA fill wants (64 consecutive pixels of one plane
+                             are one contiguous KiB); only those kernels read them.                              */
+    int32_t out_planar;   /* same for `out_q` (fast-contract REQUANT / RESIDUAL epilogues only)                  */
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
@@ -118,6 +123,9 @@ int hawq_conv2d_num_tiles(void);
 /* The LAST hawq_conv2d_num_band_tiles() tile ids are the 3x3/stride-1/pad-1 "band" kernels (fast-contract
  * int8 REQUANT layers only; hawq_conv2d refuses them for any other layer).  All other ids take any layer. */
 int hawq_conv2d_num_band_tiles(void);
+/* 1-based id of the preferred band tile that takes this layer as described (geometry, widths, epilogue,
+ * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */
+int hawq_conv2d_band_tile(const hawq_conv_args *args);
 
 /* QuantAct input case (quant_modules.py:271-274; quant_utils.py:73-97, 237-258):
  * q = clamp(rint(inv_scale * x), lo, hi); fp32 NCHW [N][3][H][W] -> int8 NHWC4 with a zero

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.test_gpu_kernels import conv_args, dev, lib, make_conv, nhwc, odyadic, orc, rand_tables, stream, unpack_q  # noqa: F401
+from tests.test_gpu_kernels import (conv_args, dev, from_planar, lib, make_conv, nhwc, odyadic, orc, pack_act,  # noqa: F401
+                                    rand_tables, stream, to_planar, unpack_q)
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +72,17 @@ def test_full_size_requant_layers(lib, orc, name, shape, bits):
             assert tile in band, f"{name}: generic tile {tile} refused"
             continue
         assert np.array_equal(unpack_q(out, (n, ho, wo, cout), bits), ref_q), f"{name}: requant, tile {tile}"
+        if tile in band:  # as the engine launches it: activations in channel-group planes
+            keep['xp'] = dev(to_planar(pack_act(x, bits)))
+            a.in_, a.in_planar = keep['xp'].data_ptr(), 1
+            out.zero_()
+            lib.call("hawq_conv2d", C.byref(a), stream())
+            assert np.array_equal(unpack_q(out, (n, ho, wo, cout), bits), ref_q), f"{name}: planar input, tile {tile}"
+        elif tile in (11, 12, 14):  # conv1 -> conv2 tensors are written as planes
+            a.out_planar = 1
+            out.zero_()
+            lib.call("hawq_conv2d", C.byref(a), stream())
+            assert np.array_equal(from_planar(out, (n, ho, wo, cout), bits), ref_q), f"{name}: planar output, tile {tile}"
         ran += 1
         del out, keep
     assert ran >= len(generic) + 1 + (1 if k == 3 and (bits == 8 or cin % 128 == 0) else 0)

@@ -56,6 +56,22 @@ def unpack_q(t, shape_nhwc, bits):
     return v.transpose(0, 3, 1, 2)
 
 
+def to_planar(packed):
+    """NHWC activation bytes (int8, or hawq4-packed) -> channel-group planes [row_bytes/16][M][16 B]
+    (include/hawq_mi355.h: in_planar / out_planar)."""
+    raw = np.ascontiguousarray(packed).view(np.uint8)
+    rb = raw.shape[-1]
+    return np.ascontiguousarray(raw.reshape(-1, rb // 16, 16).transpose(1, 0, 2))
+
+
+def from_planar(t, shape_nhwc, bits):
+    """device planes -> NCHW int64 (inverse of to_planar + unpack_q)."""
+    n, h, w, c = shape_nhwc
+    rb = c * bits // 8
+    raw = t.cpu().numpy().view(np.uint8).reshape(rb // 16, n * h * w, 16).transpose(1, 0, 2).reshape(n, h, w, rb)
+    return unpack_q(torch.from_numpy(np.ascontiguousarray(raw)), shape_nhwc, bits)
+
+
 def odyadic(orc, acc, m, ek, clamp=None):
     """oracle dyadic on a device-format (m, e|k<<8) table: (v*2^k*m)/2^e == v*m/2^(e-k)."""
     ek = np.asarray(ek, np.int64)
@@ -90,6 +106,11 @@ def conv_args(lib, x, wt, b, stride, pad, a_bits, w_bits, tile=0):
     a.in_bits, a.w_bits, a.tile = a_bits, w_bits, tile
     return a, t
 
+
+# (pixels per workgroup, channel tile, band pixels per LDS stage, needs a single 64-channel slice) of the 3x3 band
+# tiles, in tile-id order (the last ids of hawq_conv2d_num_tiles())
+BAND_GEOM = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False), (256, 128, 384, False),
+             (128, 128, 256, False)]
 
 SHAPES = [  # n, h, w, cin, cout, k, stride, pad
     (2, 14, 14, 64, 64, 1, 1, 0),
@@ -170,6 +191,19 @@ def test_conv_requant_epilogue(lib, orc, bits, out_bits, fast):
     a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), out_bits, lo, hi
     lib.call("hawq_conv2d", C.byref(a), stream())
     assert np.array_equal(unpack_q(out, (n, h, w, cout), out_bits), ref)
+    if fast:  # planar output of the staged epilogue, every generic tile; planar input is refused by those kernels
+        for tile in range(0, lib.load().hawq_conv2d_num_tiles() - lib.load().hawq_conv2d_num_band_tiles() + 1):
+            a.tile, a.out_planar = tile, 1
+            out.zero_()
+            lib.call("hawq_conv2d", C.byref(a), stream())
+            assert np.array_equal(from_planar(out, (n, h, w, cout), out_bits), ref), tile
+        a.tile, a.out_planar, a.in_planar = 1, 0, 1
+        assert lib.load().hawq_conv2d(C.byref(a), None) != 0
+        a.tile, a.in_planar = 0, 0
+    else:
+        a.out_planar = 1
+        assert lib.load().hawq_conv2d(C.byref(a), None) != 0  # the general kernels write NHWC only
+        a.out_planar = 0
     # without ReLU, symmetric clamp
     if out_bits == 8:
         a.relu = 0
@@ -194,7 +228,7 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
     assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
     ntiles, nband = lib.load().hawq_conv2d_num_tiles(), lib.load().hawq_conv2d_num_band_tiles()
     # (pixels per workgroup, channel tile, band pixels per LDS stage, needs Cin == 64) of the band tiles, in id order
-    geom = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False)]
+    geom = BAND_GEOM
     assert nband == len(geom)
     ran = 0
     for tile, (bm, bn, band_px, cin64) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
@@ -218,6 +252,14 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
             lib.call("hawq_conv2d", C.byref(a), stream())
             ref = odyadic(orc, np.maximum(acc, 0) if relu else acc, m, e, (lo, hi))
             assert np.array_equal(unpack_q(out, (n, h, w, cout), out_bits), ref), (tile, relu, out_bits)
+            # the same launch reading channel-group planes and / or writing them
+            keep['xp'] = dev(to_planar(pack_act(x, bits)))
+            for inp, outp in ((1, 0), (0, 1), (1, 1)):
+                a.in_, a.in_planar, a.out_planar = (keep['xp'] if inp else keep['x']).data_ptr(), inp, outp
+                out.zero_()
+                lib.call("hawq_conv2d", C.byref(a), stream())
+                got = from_planar(out, (n, h, w, cout), out_bits) if outp else unpack_q(out, (n, h, w, cout), out_bits)
+                assert np.array_equal(got, ref), (tile, relu, out_bits, inp, outp)
             ran += 1
     assert ran >= 3 or (bits == 4 and cin % 128)
     # a layer the band kernels cannot take is refused, not mis-computed
@@ -245,7 +287,7 @@ def test_conv3x3_band_residual(lib, orc, shape, bits, mode):
     assert ref_res.max() < 65536
     ref_q = odyadic(orc, ref_res, mq, eq, (0, 127))
     ntiles, nband = lib.load().hawq_conv2d_num_tiles(), lib.load().hawq_conv2d_num_band_tiles()
-    geom = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False)]
+    geom = BAND_GEOM
     ran = 0
     for tile, (bm, bn, band_px, one_chunk) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
         chunks = cin // 64 if bits == 8 else cin // 128
@@ -267,6 +309,12 @@ def test_conv3x3_band_residual(lib, orc, shape, bits, mode):
         assert np.array_equal(got, ref_res), tile
         assert np.array_equal(unpack_q(out_q, (n, h, w, cout), 8), ref_q), tile
         assert flags.item() == 0
+        keep['xp'] = dev(to_planar(pack_act(x, bits)))
+        a.in_, a.in_planar, a.out_planar = keep['xp'].data_ptr(), 1, 1
+        out_res.zero_(), out_q.zero_()
+        lib.call("hawq_conv2d", C.byref(a), stream())
+        got = out_res.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2)
+        assert np.array_equal(got, ref_res) and np.array_equal(from_planar(out_q, (n, h, w, cout), 8), ref_q), tile
         ran += 1
     assert ran >= 1 or (bits == 4 and cin % 128)
 
