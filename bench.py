@@ -153,6 +153,9 @@ def launch_model(name, rows, batch):
         parts.append(rows[base])
     if name.endswith("+identity"):
         parts.append(rows[base.rsplit(".", 1)[0] + ".quant_identity_convbn"])
+    for extra in name.split("+")[1:]:   # a fused launch covers a second layer (expand conv + next unit's reduce conv)
+        if extra in rows:
+            parts.append(rows[extra])
     if name in ("hawq_quantize_input", "hawq_stem_fused"):
         parts.append(rows["quant_input"])
     if name in ("hawq_stem_conv7", "hawq_stem_fused"):
@@ -273,6 +276,7 @@ def main():
                        "residual_uint16_overflow": overflow,
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "exact_tie_requant_launches": eng.n_tie,
                        "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
+                       "fused_expand_reduce_launches": len(eng.er_choice), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
                        "concurrent_sub_batches": eng.chains},
             # all logits of this rank's images against the CPU oracle's golden logits of the same workload
             "parity": {"gpu_logits_bit_equal_oracle": parity, "images_compared": local_batch if parity is not None else 0,

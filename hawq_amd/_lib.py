@@ -38,6 +38,11 @@ class ConvArgs(C.Structure):
     ]
 
 
+class ExpandReduceArgs(C.Structure):
+    """struct hawq_expand_reduce_args (include/hawq_mi355.h)."""
+    _fields_ = [("expand", ConvArgs), ("reduce", ConvArgs), ("tile", i32)]
+
+
 # name -> (argtypes); every function returns int except hawq_last_error
 SIGNATURES = {
     "hawq_abi_version": [],
@@ -46,6 +51,8 @@ SIGNATURES = {
     "hawq_conv2d_num_tiles": [],
     "hawq_conv2d_num_band_tiles": [],
     "hawq_conv2d_band_tile": [C.POINTER(ConvArgs)],
+    "hawq_conv_expand_reduce": [C.POINTER(ExpandReduceArgs), vp],
+    "hawq_conv_expand_reduce_variants": [C.POINTER(ExpandReduceArgs)],
     "hawq_quantize_input": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "hawq_stem_conv7": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_stem_fused": [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32,

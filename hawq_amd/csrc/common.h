@@ -114,3 +114,28 @@ __device__ __forceinline__ uint32_t pack4_i8(int a, int b, int c, int d) {
 __device__ __forceinline__ uint32_t pack8_u4(const int *q) {
     return pack4_i8(q[0], q[1], q[2], q[3]) | (pack4_i8(q[4], q[5], q[6], q[7]) << 4);
 }
+
+// ---- shared device helpers of the conv kernels (conv_igemm.hip, fused_er.hip) ---------------------------
+// MFMA C/D row i of a 32x32 tile lives in (reg, half) with i = (reg&3) + 8*(reg>>2) + 4*half.
+// Reading weight row cperm(i) as MFMA row i makes lane-half h own channels 16h..16h+15.
+__device__ __forceinline__ int cperm(int i) { return (((i >> 2) & 1) << 4) + (i & 3) + ((i >> 3) << 2); }
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// 4 ints already clamped to the int8 range -> one dword (byte 0 = first): 2x v_cvt_pk_i16_i32 + v_perm
+__device__ __forceinline__ int pack4_fast(int a, int b, int c, int d) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 lo = __builtin_amdgcn_cvt_pk_i16(a, b), hi = __builtin_amdgcn_cvt_pk_i16(c, d);
+    return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
+}
+// two non-negative ints -> saturating uint16 pair (v_cvt_pk_u16_u32)
+__device__ __forceinline__ int pack2_u16_sat(int a, int b) {
+    typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_cvt_pk_u16((unsigned)a, (unsigned)b);
+    return __builtin_bit_cast(int, r);
+}

@@ -71,11 +71,6 @@ struct Cfg {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must fill whole staging passes");
 };
 
-// MFMA C/D row i of a 32x32 tile lives in (reg, half) with i = (reg&3) + 8*(reg>>2) + 4*half.
-// Reading weight row cperm(i) as MFMA row i makes lane-half h own channels 16h..16h+15.
-__device__ __forceinline__ int cperm(int i) { return (((i >> 2) & 1) << 4) + (i & 3) + ((i >> 3) << 2); }
-
-__device__ __forceinline__ int lds_off(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
 // 8 bytes of hawq4 (16 channels) -> 16 int8.  Unsigned: zero-extended.  Signed weights come
 // out as value*16 (nibble moved to the top of its byte); the accumulator is shifted back by 4
@@ -240,10 +235,6 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
 // branch's MFMAs.
 __device__ __attribute__((aligned(16))) const int g_zero16[4] = {0, 0, 0, 0};
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Hand-issued LDS fragment reads.  hipcc treats every LDS-DMA instruction as a pending FLAT access and from then
 // on only ever emits `s_waitcnt lgkmcnt(0)` (measured on a toy kernel: lgkmcnt(2) without, lgkmcnt(0) with one
@@ -469,18 +460,6 @@ __device__ __forceinline__ void run_segment(v16i (&acc)[C::CT][C::PT], const uin
 
 __device__ __forceinline__ v4i ld4(const int32_t *p) { return *reinterpret_cast<const v4i *>(p); }
 
-// 4 ints already clamped to the int8 range -> one dword (byte 0 = first): 2x v_cvt_pk_i16_i32 + v_perm
-__device__ __forceinline__ int pack4_fast(int a, int b, int c, int d) {
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    const s2 lo = __builtin_amdgcn_cvt_pk_i16(a, b), hi = __builtin_amdgcn_cvt_pk_i16(c, d);
-    return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
-}
-// two non-negative ints -> saturating uint16 pair (v_cvt_pk_u16_u32)
-__device__ __forceinline__ int pack2_u16_sat(int a, int b) {
-    typedef unsigned short u2 __attribute__((ext_vector_type(2)));
-    const u2 r = __builtin_amdgcn_cvt_pk_u16((unsigned)a, (unsigned)b);
-    return __builtin_bit_cast(int, r);
-}
 
 // =============================================================== exact general epilogue (BITS == 0)
 // Direct per-lane global accesses, dyadic_rne everywhere: any e in [1,62], any pre-shift, ties

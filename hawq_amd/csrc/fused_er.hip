@@ -1,0 +1,364 @@
+// Fused "expand -> reduce" launch for gfx950 (MI355X): the 1x1 expand conv of bottleneck unit i with its residual
+// epilogue AND the 1x1 reduce conv of unit i+1 in one kernel.
+//
+// Reference graph (q_resnet.py:231-260): ... conv3(i) -> x + identity -> quant_act_int32 -> ReLU |unit i+1| quant_act
+// -> conv1 -> ReLU -> quant_act1.  Launched separately, conv3's kernel is bound by memory (uint16 residual in and out)
+// and epilogue VALU while the matrix pipe idles (2-6 % busy), writes the 8-bit block input `q` of unit i+1, and conv1's
+// kernel reads it straight back - a short latency-bound GEMM.  Here a workgroup owns BM pixels and walks the expand
+// conv's C3 output channels in slices of 64:
+//     GEMM1  acc1[BM x 64]  = x2[BM x C] . W3[slice][C]^T              (K = C, operands: resident x2 tile, W3 slice)
+//     epi 1  o = ReLU(requant(acc1) + requant(residual)); residual slice out (uint16); q = QuantAct_{i+1}(o) -> LDS
+//     GEMM2  acc2[BM x C'] += q[BM x 64] . W1[:, slice]^T              (K = 64 of the reduce conv's K = C3)
+// and after the last slice  y = QuantAct1(ReLU(acc2 + bias1)) -> int8 [M][C'].  The block input q never reaches memory
+// (one write + one read of M x C3 bytes per unit) and the reduce conv's MACs run under the expand epilogue's
+// memory / VALU time.  Every rounding point of SURVEY.md App. A is kept: each residual branch is requantised separately,
+// summed un-clamped (quant_utils.py:416-456), q is the block-input QuantAct of the stored 16-bit value
+// (quant_modules.py:288-293), the reduce conv accumulates exact int32 over all C3 channels before its own requant.
+//
+// int8 x int8, fast-contract tables (see hawq_conv_args.fast_tables; exact-tie mode as a separate instantiation),
+// uint16 residuals, C = C' in {64, 128, 256} (ResNet50 stages 1-3).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct ERP {
+    const uint8_t *x2, *w3, *w1;
+    const int32_t *ctab3, *ctab1;
+    const uint16_t *res_in;
+    uint16_t *res_out;
+    uint8_t *y;
+    int M, C3;
+    int m_id_s, e_id_s, mq, eq, q_hi;  // scalar tables: identity pass-through, QuantAct of unit i+1 (q >= 0: post-ReLU)
+    int y_lo, y_hi;                    // clamp of the reduce conv's QuantAct (ReLU folded into y_lo)
+    int y_planar;
+    int32_t *flags;
+};
+
+__device__ __attribute__((aligned(16))) const int g_er_zero16[4] = {0, 0, 0, 0};
+
+// C: channels of the expand conv's input = of the reduce conv's output.  WM: pixel MFMA tiles (32 pixels) per
+// workgroup = waves along the pixel axis; 2 waves along the channel axis.  NSW: weight ring stages.
+template <int C_, int WM_, int MINB_>
+struct ERCfg {
+    static constexpr int C = C_, WM = WM_, MINB = MINB_;
+    static constexpr int BM = 32 * WM, NW = 2 * WM, NT = 64 * NW;
+    static constexpr int KC = C / 64;          // 64-byte chunks of GEMM1's K
+    static constexpr int CT2 = C / 64;         // 32-channel MFMA tiles per wave in GEMM2 (2 waves across the C channels)
+    static constexpr int RPP = NT / 4;         // operand rows per LDS-DMA pass (4 lanes x 16 B per 64-byte row)
+    static constexpr int NSW = 3;
+    static constexpr int WSTAGE = 64 * C;      // W3 slice [KC][64 rows][64 B]  ==  W1 slice [C rows][64 B]
+    static constexpr int WPASS = WSTAGE / (RPP * 64);   // LDS-DMA instructions per thread per ring stage
+    static constexpr int X2_BYTES = BM * C;
+    static constexpr int Q_BYTES = BM * 64, RES_BYTES = BM * 128;
+    // LDS map
+    static constexpr int OFF_X2 = 0;
+    static constexpr int OFF_RING = OFF_X2 + X2_BYTES;
+    static constexpr int OFF_Q = OFF_RING + NSW * WSTAGE;       // [2][BM][64 B]
+    static constexpr int OFF_RES = OFF_Q + 2 * Q_BYTES;         // [2][BM][64] uint16
+    static constexpr int OFF_CT3 = OFF_RES + 2 * RES_BYTES;     // [2][64][16 B]
+    static constexpr int OFF_CT1 = OFF_CT3 + 2 * 1024;          // [C][16 B]
+    static constexpr int LDS_BYTES = OFF_CT1 + C * 16;
+    static_assert(WSTAGE % (RPP * 64) == 0 && BM == RPP, "tile rows must fill whole LDS-DMA passes");
+    static_assert(BM * C <= NSW * WSTAGE, "the output tile is staged on the weight ring");
+};
+
+__device__ __forceinline__ void dma16(const char *src, char *dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const char *src, char *dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+}
+__device__ __forceinline__ DyNt ctab_entry(const char *ctab_lds, int ch) {
+    const v4i t = *reinterpret_cast<const v4i *>(ctab_lds + ch * 16);
+    DyNt d;
+    d.m = t.x, d.s = t.y & 0xff, d.k = t.y >> 8;
+    d.add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
+    return d;
+}
+
+template <class F, bool TIE>
+__global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MODE = TIE ? 2 : 0;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_m = wave % F::WM, wave_c = wave / F::WM;   // GEMM1: 32 px x 32 ch per wave; GEMM2: 32 px x C/2 ch
+    const int l31 = lane & 31, h = lane >> 5;
+    const int lrow = t >> 2, lslot = t & 3;
+    const int m0 = blockIdx.x * F::BM;
+    const int nslices = p.C3 >> 6;
+    const char *zero = reinterpret_cast<const char *>(g_er_zero16);
+    char *x2t = smem + F::OFF_X2, *ring = smem + F::OFF_RING, *qt = smem + F::OFF_Q, *rest = smem + F::OFF_RES;
+    char *ct3 = smem + F::OFF_CT3, *ct1 = smem + F::OFF_CT1;
+
+    // ---------------------------------------------------------------- LDS-DMA issue helpers (all waves, uniform counts)
+    const int sw = (lslot ^ ((lrow >> 2) & 3)) << 4;   // source-side swizzle of this thread's 16-byte slot (rows lrow + k * RPP: same)
+    static_assert((F::RPP & 15) == 0, "the swizzle of row r + RPP equals that of row r");
+    auto issue_w3 = [&](int j, int stage) {   // rows j*64 .. j*64+63 of W3 [C3][C], as KC chunks of [64 rows][64 B]
+        char *dst = ring + stage * F::WSTAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < F::WPASS; ++i) {
+            const int idx = i * F::RPP + lrow, chunk = idx >> 6, row = idx & 63;
+            dma16((const char *)p.w3 + (size_t)(j * 64 + row) * F::C + chunk * 64 + sw, dst + i * (F::RPP * 64));
+        }
+    };
+    auto issue_w1 = [&](int j, int stage) {   // columns j*64 .. j*64+63 of W1 [C][C3], as [C rows][64 B]
+        char *dst = ring + stage * F::WSTAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < F::WPASS; ++i) {
+            const int row = i * F::RPP + lrow;
+            dma16((const char *)p.w1 + (size_t)row * p.C3 + j * 64 + sw, dst + i * (F::RPP * 64));
+        }
+    };
+    auto issue_res = [&](int j) {   // residual slice [BM][64] uint16, 16-byte chunks swizzled by the pixel row; + ctab3 slice
+        char *dst = rest + (j & 1) * F::RES_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int base = (i * F::NW + wave) * 64, idx = base + lane;
+            const int row = idx >> 3, jj = idx & 7;
+            const int grow = (m0 + row < p.M) ? m0 + row : m0;
+            dma16((const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
+        }
+        dma4((const char *)p.ctab3 + (size_t)j * 1024 + (wave & 3) * 256 + lane * 4, ct3 + (j & 1) * 1024 + (wave & 3) * 256);
+    };
+    constexpr int N_A = F::WPASS + 3;   // loads per thread of one {W3, residual, ctab3} group
+
+    // ---------------------------------------------------------------- prologue
+    {   // resident x2 tile: KC chunks of [BM pixel rows][64 B]
+        const bool v = m0 + lrow < p.M;
+#pragma unroll
+        for (int kc = 0; kc < F::KC; ++kc)
+            dma16(v ? (const char *)p.x2 + (size_t)(m0 + lrow) * F::C + kc * 64 + sw : zero, x2t + kc * (F::BM * 64) + wave * 1024);
+        // ctab of the reduce conv: C entries of 16 B = C / 64 wave pieces (the waves' load counts may differ here: every
+        // counted wait below only ever leaves a wave's YOUNGEST loads in flight, which are the same for all waves)
+        for (int pc = wave; pc < F::C / 64; pc += F::NW)
+            dma16((const char *)p.ctab1 + (size_t)(pc * 64 + lane) * 16, ct1 + pc * 1024);
+    }
+    issue_w3(0, 0);
+    issue_res(0);
+    issue_w1(0, 1);
+
+    v16i acc2[F::CT2];
+#pragma unroll
+    for (int c = 0; c < F::CT2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
+
+    const int arow = wave_m * 32 + l31;                           // this lane's pixel row (both GEMMs, both epilogues)
+    const int wrow1 = wave_c * 32 + cperm(l31);                   // GEMM1: W3 slice row
+    const int lch = wave_c * 32 + h * 16;                         // slice-local first channel of this lane's 16 outputs
+    const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    const unsigned rowmask = (m0 + arow < p.M) ? 0xffffffffu : 0u;
+    unsigned oor = 0;
+
+    wait_vmcnt<F::WPASS>();   // everything but W1(0) has landed
+    // ring stage of W3(j) is (2j) % 3, of W1(j) is (2j + 1) % 3
+    for (int j = 0; j < nslices; ++j) {
+        const int st3 = (2 * j) % 3, st1 = (2 * j + 1) % 3;
+        __builtin_amdgcn_s_barrier();   // B1(j): W3(j), residual(j), ctab3(j) visible; GEMM2(j-1) reads and its stores' LDS reads done
+        if (j + 1 < nslices) {
+            issue_w3(j + 1, (2 * j + 2) % 3);
+            issue_res(j + 1);
+        }
+        // ------------------------------------------------------------ GEMM1
+        v16i acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0;
+        {
+            const char *w3s = ring + st3 * F::WSTAGE;
+#pragma unroll
+            for (int kc = 0; kc < F::KC; ++kc)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const v4i wf = *reinterpret_cast<const v4i *>(w3s + kc * 4096 + lds_off(wrow1, 2 * ks + h));
+                    const v4i af = *reinterpret_cast<const v4i *>(x2t + kc * (F::BM * 64) + lds_off(arow, 2 * ks + h));
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc1, 0, 0, 0);
+                }
+        }
+        // ------------------------------------------------------------ epilogue 1: residual add, ReLU, next QuantAct
+        {
+            char *rb = rest + (j & 1) * F::RES_BYTES + arow * 128;
+            const char *ctb = ct3 + (j & 1) * 1024;
+            v4i rin[2];
+            rin[0] = *reinterpret_cast<const v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4));
+            rin[1] = *reinterpret_cast<const v4i *>(rb + ((((lch >> 3) + 1) ^ (arow & 7)) << 4));
+            int rpack[8], qpack[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned w0 = (unsigned)rin[g >> 1][(g & 1) * 2], w1 = (unsigned)rin[g >> 1][(g & 1) * 2 + 1];
+                const int idin[4] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+                int o[4], qv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const DyNt dm = ctab_entry(ctb, lch + 4 * g + k);
+                    const int a = dyadic_mode<MODE>(acc1[4 * g + k], dm);
+                    const int b = dyadic_mode<MODE>(idin[k], dids);
+                    o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
+                    qv[k] = min(dyadic_mode<MODE>(o[k], dq), p.q_hi);      // o >= 0, m >= 0: q >= 0
+                }
+                oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask;
+                rpack[2 * g] = pack2_u16_sat(o[0], o[1]);
+                rpack[2 * g + 1] = pack2_u16_sat(o[2], o[3]);
+                qpack[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+            }
+            const v4i ra = {rpack[0], rpack[1], rpack[2], rpack[3]}, rc = {rpack[4], rpack[5], rpack[6], rpack[7]};
+            *reinterpret_cast<v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4)) = ra;
+            *reinterpret_cast<v4i *>(rb + ((((lch >> 3) + 1) ^ (arow & 7)) << 4)) = rc;
+            const v4i qw = {qpack[0], qpack[1], qpack[2], qpack[3]};
+            *reinterpret_cast<v4i *>(qt + (j & 1) * F::Q_BYTES + lds_off(arow, lch >> 4)) = qw;
+        }
+        // W1(j) was issued before this slice's {W3, residual, ctab3}(j+1) group: wait for it, leave the group in flight
+        if (j + 1 < nslices) wait_vmcnt<N_A>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // B2(j): q(j) and the new residual slice visible, W1(j) visible, GEMM1(j) reads done
+        // ------------------------------------------------------------ GEMM2 partial sum over this slice's 64 channels
+        {
+            const char *w1s = ring + st1 * F::WSTAGE, *qs = qt + (j & 1) * F::Q_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const v4i af = *reinterpret_cast<const v4i *>(qs + lds_off(arow, 2 * ks + h));
+#pragma unroll
+                for (int c = 0; c < F::CT2; ++c) {
+                    const v4i wf = *reinterpret_cast<const v4i *>(w1s + lds_off(wave_c * (F::CT2 * 32) + c * 32 + cperm(l31), 2 * ks + h));
+                    acc2[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc2[c], 0, 0, 0);
+                }
+            }
+        }
+        // Stores count on vmcnt like loads and may retire before OLDER loads: every load that a later counted wait
+        // targets must have landed before a store is issued.  {W3, residual, ctab3}(j+1) had GEMM1 + epilogue + GEMM2.
+        wait_vmcnt<0>();
+        {   // new residual slice -> memory, whole 128-byte rows
+            const char *src = rest + (j & 1) * F::RES_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = t + F::NT * i, row = idx >> 3, jj = idx & 7;
+                if (m0 + row < p.M)
+                    *reinterpret_cast<v4i *>((char *)p.res_out + ((size_t)(m0 + row) * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4)) =
+                        *reinterpret_cast<const v4i *>(src + idx * 16);
+            }
+        }
+        if (j + 1 < nslices) issue_w1(j + 1, (2 * j + 3) % 3);   // into the stage GEMM1(j) read (all waves are past B2(j))
+    }
+    if ((oor >> 16) != 0) atomicOr(p.flags, 1);
+    // ---------------------------------------------------------------- epilogue 2: the reduce conv's QuantAct
+    __syncthreads();   // all GEMM2 fragment reads done: the ring becomes the output staging tile [BM][C B]
+    {
+        constexpr int CPR = F::C / 16;   // 16-byte chunks per output row
+        char *yt = ring;
+#pragma unroll
+        for (int c = 0; c < F::CT2; ++c) {
+            const int ch0 = wave_c * (F::CT2 * 32) + c * 32 + h * 16;
+            int w[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int qv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    qv[k] = med3i(dyadic_mode<MODE>(acc2[c][4 * g + k], ctab_entry(ct1, ch0 + 4 * g + k)), p.y_lo, p.y_hi);
+                w[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+            }
+            const v4i ww = {w[0], w[1], w[2], w[3]};
+            *reinterpret_cast<v4i *>(yt + (arow * CPR + ((ch0 >> 4) ^ (arow & (CPR - 1)))) * 16) = ww;
+        }
+        __syncthreads();
+        if (p.y_planar) {   // channel-group planes [C / 16][M][16 B] (hawq_conv_args.out_planar)
+#pragma unroll
+            for (int i = 0; i < F::BM * CPR / F::NT; ++i) {
+                const int idx = t + F::NT * i, ch = idx / F::BM, row = idx % F::BM;
+                if (m0 + row < p.M)
+                    *reinterpret_cast<v4i *>((char *)p.y + ((size_t)ch * p.M + (m0 + row)) * 16) =
+                        *reinterpret_cast<const v4i *>(yt + (row * CPR + (ch ^ (row & (CPR - 1)))) * 16);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < F::BM * CPR / F::NT; ++i) {
+                const int idx = t + F::NT * i, row = idx / CPR, jj = idx % CPR;
+                if (m0 + row < p.M)
+                    *reinterpret_cast<v4i *>((char *)p.y + (size_t)(m0 + row) * F::C + ((jj ^ (row & (CPR - 1))) << 4)) =
+                        *reinterpret_cast<const v4i *>(yt + idx * 16);
+            }
+        }
+    }
+}
+
+using E64 = ERCfg<64, 2, 3>;      // stage 1: 64 pixels, 4 waves, 43 KiB of LDS -> 3 workgroups per CU
+using E128 = ERCfg<128, 2, 2>;    // stage 2: 64 pixels, 4 waves, 62 KiB
+using E128W = ERCfg<128, 4, 1>;   // stage 2: 128 pixels, 8 waves (the weight slices are streamed once per 128 pixels)
+using E256 = ERCfg<256, 4, 1>;    // stage 3: 128 pixels, 8 waves, 134 KiB
+constexpr int NUM_ER = 4;
+
+typedef void (*ERFn)(const ERP);
+struct ERInfo { ERFn fn[2]; int c, bm, nt, lds; };
+#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>}, F::C, F::BM, F::NT, F::LDS_BYTES}
+const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E128), ER_ENTRY(E128W), ER_ENTRY(E256)};
+
+bool conv_is_1x1_int8_fast(const hawq_conv_args &a) {
+    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 && !a.in2 &&
+           !a.in_planar;
+}
+
+// variant index (into kER) for this pair, or -1.  `tile` 0 = default, 1.. = the variants that take channel count C in table order
+int er_variant(const hawq_expand_reduce_args *a) {
+    const hawq_conv_args &e = a->expand, &r = a->reduce;
+    if (!conv_is_1x1_int8_fast(e) || !conv_is_1x1_int8_fast(r)) return -1;
+    if (e.epilogue != HAWQ_EPI_RESIDUAL || r.epilogue != HAWQ_EPI_REQUANT) return -1;
+    if (!e.res_in || e.res_in_bits != 16 || !e.res_out || e.res_out_bits != 16 || !e.flags || !e.ctab || !r.ctab || !r.out_q) return -1;
+    if (r.out_bits != 8 || e.out_bits != 8) return -1;
+    if (r.Cin != e.Cout || r.Cout != e.Cin || r.N != e.N || r.H != e.H || r.W != e.W || e.Cout % 64) return -1;
+    int nth = 0, first = -1;
+    for (int i = 0; i < NUM_ER; ++i)
+        if (kER[i].c == e.Cin) {
+            if (first < 0) first = i;
+            if (++nth == a->tile) return i;
+        }
+    return a->tile == 0 ? first : -1;
+}
+
+}  // namespace
+
+extern "C" int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *a) {
+    if (!a) return 0;
+    hawq_expand_reduce_args q = *a;
+    q.tile = 0;
+    if (er_variant(&q) < 0) return 0;
+    int n = 0;
+    for (int i = 0; i < NUM_ER; ++i) n += kER[i].c == a->expand.Cin;
+    return n;
+}
+
+extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *stream) {
+    HAWQ_REQUIRE(a != nullptr, "hawq_conv_expand_reduce: null args");
+    const int v = er_variant(a);
+    HAWQ_REQUIRE(v >= 0, "hawq_conv_expand_reduce: this pair of layers cannot be fused (need 1x1/stride-1 int8 fast-contract convs, "
+                         "uint16 residual in and out, Cin in {64,128,256}, reduce.Cin == expand.Cout, reduce.Cout == expand.Cin; tile %d)", a->tile);
+    const hawq_conv_args &e = a->expand, &r = a->reduce;
+    auto e_fast = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62; };
+    HAWQ_REQUIRE(e.mq >= 0 && e_fast(e.eq) && e.m_id_scalar >= 0 && e_fast(e.e_id_scalar), "hawq_conv_expand_reduce: scalar tables outside the fast contract");
+    HAWQ_REQUIRE(e.q_lo <= 0, "hawq_conv_expand_reduce: the block-input QuantAct clamp must admit 0");
+    ERP p;
+    p.x2 = (const uint8_t *)e.in, p.w3 = (const uint8_t *)e.wgt, p.w1 = (const uint8_t *)r.wgt;
+    p.ctab3 = e.ctab, p.ctab1 = r.ctab;
+    p.res_in = (const uint16_t *)e.res_in, p.res_out = (uint16_t *)e.res_out;
+    p.y = (uint8_t *)r.out_q;
+    const long long M = (long long)e.N * e.H * e.W;
+    HAWQ_REQUIRE(M > 0 && M < (1ll << 30), "hawq_conv_expand_reduce: bad problem size");
+    p.M = (int)M, p.C3 = e.Cout;
+    p.m_id_s = e.m_id_scalar, p.e_id_s = e.e_id_scalar, p.mq = e.mq, p.eq = e.eq, p.q_hi = e.q_hi;
+    p.y_lo = r.relu && r.q_lo < 0 ? 0 : r.q_lo, p.y_hi = r.q_hi;
+    p.y_planar = r.out_planar;
+    p.flags = e.flags;
+    const ERInfo &ei = kER[v];
+    static const bool attrs = [] {
+        bool good = true;
+        for (const ERInfo &k : kER)
+            for (int i = 0; i < 2; ++i)
+                good &= hipFuncSetAttribute((const void *)k.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, k.lds) == hipSuccess;
+        return good;
+    }();
+    HAWQ_REQUIRE(attrs, "hawq_conv_expand_reduce: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    const bool tie = ((e.fast_tables | r.fast_tables) & 4) != 0;
+    hipLaunchKernelGGL(ei.fn[tie ? 1 : 0], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}

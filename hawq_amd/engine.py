@@ -105,10 +105,10 @@ class IntegerEngine:
         if _parent is not None:  # a chain of a multi-chain engine: shares parameters, owns stream + buffers
             self.__dict__.update({k: v for k, v in _parent.__dict__.items()
                                   if k in ("model", "dev", "res_bits", "from_buffers", "keep_acc", "fast", "autotune",
-                                           "flags", "P", "planar")})
+                                           "flags", "P", "planar", "fuse_stages")})
             self.use_graph, self.chains, self.subs = False, 1, []
             self.stream = torch.cuda.Stream(device=self.dev)
-            self.tile_choice = {}
+            self.tile_choice, self.er_choice = {}, {}
             self._batch = self._graph = None
             return
         if not model.is_frozen():
@@ -126,7 +126,10 @@ class IntegerEngine:
         self.autotune = autotune  # pick each conv launch's tile configuration by timing it once per batch shape
         # conv1 -> 3x3 conv2 tensors as channel-group planes (include/hawq_mi355.h: in_planar / out_planar)
         self.planar = not keep_accumulators and not os.environ.get("HAWQ_NO_PLANAR")
+        # expand conv of unit i + reduce conv of unit i+1 in one launch (hawq_conv_expand_reduce) in these stages
+        self.fuse_stages = set() if keep_accumulators else {int(v) for v in os.environ.get("HAWQ_FUSE_STAGES", "1,2,3").split(",") if v}
         self.tile_choice = {}
+        self.er_choice = {}
         # chains > 1: the batch is split into independent sub-batches whose launch chains run on separate
         # streams inside ONE hipGraph, so that one chain's kernel tails / prologues / epilogues overlap the
         # other's work (the late layers launch fewer workgroups than there are CUs).  0 = choose 1, 2 or 3 by
@@ -289,6 +292,39 @@ class IntegerEngine:
             q.epilogue, q.out_q = _lib.EPI_REQUANT, 1
         return _lib.load().hawq_conv2d_band_tile(C.byref(q)) != 0
 
+    def _try_fuse(self, a, u, nxt, N, ho, wo, keep):
+        """Expand conv launch `a` of unit `u` (RESIDUAL epilogue, already filled) + reduce conv of unit `nxt`:
+        returns (ExpandReduceArgs, output tensor, out_bits, planar) or None if the library does not take the pair."""
+        if nxt is None or nxt['resize'] or u['resize'] or len(nxt['convs']) != 3 or not a.fast_tables:
+            return None
+        if int(u['name'].split('.')[0][len('stage'):]) not in self.fuse_stages:
+            return None
+        ent = nxt['convs'][0]
+        c = ent['conv']
+        if not ent.get('fast', False) or ent['out_bits'] != 8 or nxt['a_bits'] != 8 or c.w_bits != 8:
+            return None
+        er = _lib.ExpandReduceArgs()
+        C.memmove(C.byref(er.expand), C.byref(a), C.sizeof(a))
+        er.expand.out_q = None   # the 8-bit block input of the next unit stays on chip
+        r = er.reduce
+        r.wgt, r.bias = c.w.data_ptr(), c.bias.data_ptr()
+        r.N, r.H, r.W, r.Cin, r.Cout, r.KH, r.KW, r.stride, r.pad = N, ho, wo, c.cin, c.cout, c.kh, c.kw, c.stride, c.pad
+        r.in_bits, r.w_bits = 8, 8
+        r.m, r.e, r.ctab = ent['m'].data_ptr(), ent['e'].data_ptr(), ent['ctab'].data_ptr()
+        r.flags = self.flags.data_ptr()
+        r.epilogue, r.relu = _lib.EPI_REQUANT, 1
+        r.out_bits, r.q_lo, r.q_hi = 8, ent['rng'][0], ent['rng'][1]
+        r.fast_tables = 5 if ent.get('tie', False) else 1
+        r.out_q = 1  # placeholder for the applicability query
+        if _lib.load().hawq_conv_expand_reduce_variants(C.byref(er)) == 0:
+            return None
+        out = self._alloc(N * ho * wo * c.cout, torch.uint8)
+        r.out_q = out.data_ptr()
+        planar = self.planar and self._band_takes(nxt['convs'][1], N, ho, wo, 8, False, nxt)
+        r.out_planar = int(planar)
+        keep += [out, er]
+        return er, out, 8, planar
+
     def _alloc(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.dev)
 
@@ -352,7 +388,7 @@ class IntegerEngine:
             self._ops, self._keep, self._batch, self._graph = _OpList(), [], (N, H, W), None
             self.n_fast, self.n_conv, self.n_k0, self.n_tie = (self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0,
                                                               self.subs[0].n_tie)
-            self.tile_choice = self.subs[0].tile_choice
+            self.tile_choice, self.er_choice = self.subs[0].tile_choice, self.subs[0].er_choice
             return
         self.subs = []
         ops, keep = _OpList(), []
@@ -401,11 +437,20 @@ class IntegerEngine:
         keep += [xq, stem16, stem_acc, res, qa]
         h, w = H1, W1
         res_bits_in = 16
+        fused_in = None
+        self._er_args, self._er_names = [], []
         for ui, u in enumerate(units):
             nxt = units[ui + 1] if ui + 1 < len(units) else None
             x_in, x_bits, hin, win, x_planar = qa, u['a_bits'], h, w, False
             for ci, ent in enumerate(u['convs']):
                 c = ent['conv']
+                if ci == 0 and fused_in is not None:   # this unit's reduce conv ran inside the previous unit's launch
+                    x_in, x_bits, x_planar = fused_in
+                    hin, win = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
+                    fused_in = None
+                    self.n_fast += 1
+                    self.n_conv += 1
+                    continue
                 ho, wo = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
                 a = _lib.ConvArgs()
                 a.in_, a.wgt, a.bias = x_in.data_ptr(), c.w.data_ptr(), c.bias.data_ptr()
@@ -456,18 +501,29 @@ class IntegerEngine:
                     new_res = self._alloc(N * ho * wo * c.cout, rdt) if need_res else None
                     if new_res is not None:
                         a.res_out, a.res_out_bits = new_res.data_ptr(), self.res_bits
+                    new_qa = None
                     if nxt is not None:
-                        new_qa = self._alloc(N * ho * wo * c.cout * nxt['a_bits'] // 8, torch.uint8)
-                        a.out_q, a.out_bits = new_qa.data_ptr(), nxt['a_bits']
+                        a.out_bits = nxt['a_bits']
                         a.q_lo, a.q_hi, a.mq, a.eq = nxt['a_rng'][0], nxt['a_rng'][1], nxt['mq'], nxt['eq']
-                    else:
-                        new_qa = None
-                    keep += [new_res, new_qa]
+                    keep.append(new_res)
                 if self.keep_acc:
                     self._add_acc_tap(ops, keep, a, tap_name, N, ho, wo, c.cout)
                     if ci == len(u['convs']) - 1 and u['resize']:
                         self._add_ident_tap(ops, keep, u, qa, N, h, w, ho, wo)
                 keep.append(a)
+                fz = self._try_fuse(a, u, nxt, N, ho, wo, keep) if (ci == len(u['convs']) - 1 and not self.keep_acc) else None
+                if fz is None and ci == len(u['convs']) - 1 and nxt is not None:
+                    new_qa = self._alloc(N * ho * wo * c.cout * nxt['a_bits'] // 8, torch.uint8)
+                    a.out_q = new_qa.data_ptr()
+                    keep.append(new_qa)
+                if fz is not None:
+                    er, fout, fbits, fplanar = fz
+                    fused_in = (fout, fbits, fplanar)
+                    self._er_args.append(er)
+                    self._er_names.append(tap_name)
+                    ops.next_name = tap_name + "+" + nxt['name'] + ".quant_convbn1"
+                    ops.append(partial(_lib.call, "hawq_conv_expand_reduce", C.byref(er), sp))
+                    continue
                 self._conv_args.append(a)
                 self._conv_names.append(tap_name)
                 ops.next_name = tap_name + ("+identity" if (a.in2 is not None) else "")
@@ -547,6 +603,9 @@ class IntegerEngine:
             for name, a, tid in zip(self._conv_names, self._conv_args, ids):
                 a.tile = tid
                 self.tile_choice[name] = tid
+            for k, (name, er) in enumerate(zip(self._er_names, self._er_args)):
+                er.tile = int(os.environ.get("HAWQ_ER_TILES", "0." * len(self._er_args)).split(".")[k] or 0)
+                self.er_choice[name] = er.tile
             return
         with torch.cuda.stream(self.stream):
             self._launch_all()  # every buffer holds valid data
@@ -575,6 +634,29 @@ class IntegerEngine:
                     print(f"[autotune N={a.N}] {name}: best {best_t}  us per tile: {' '.join(log)}", file=sys.stderr)
                 a.tile = best_t
                 self.tile_choice[name] = best_t
+            fixed_er = os.environ.get("HAWQ_ER_TILES")
+            for k, (name, er) in enumerate(zip(self._er_names, self._er_args)):
+                if fixed_er:
+                    er.tile = int(fixed_er.split(".")[k])
+                    self.er_choice[name] = er.tile
+                    continue
+                nvar = _lib.load().hawq_conv_expand_reduce_variants(C.byref(er))
+                times = {}
+                for rnd in range(2):
+                    for tile in range(1, nvar + 1):
+                        er.tile = tile
+                        _lib.call("hawq_conv_expand_reduce", C.byref(er), sp)
+                        _lib.call("hawq_event_record", e0, sp)
+                        for _ in range(reps):
+                            _lib.call("hawq_conv_expand_reduce", C.byref(er), sp)
+                        _lib.call("hawq_event_record", e1, sp)
+                        _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
+                        times[tile] = min(times.get(tile, ms.value), ms.value)
+                er.tile = min(times, key=times.get)
+                if os.environ.get("HAWQ_AUTOTUNE_LOG"):
+                    log = [f"{t}:{v / reps * 1e3:.1f}" for t, v in times.items()]
+                    print(f"[autotune N={er.expand.N}] {name}+next reduce (fused): best {er.tile}  us per variant: {' '.join(log)}", file=sys.stderr)
+                self.er_choice[name] = er.tile
         _lib.call("hawq_event_destroy", e0)
         _lib.call("hawq_event_destroy", e1)
         torch.cuda.synchronize(self.dev)

@@ -127,6 +127,22 @@ int hawq_conv2d_num_band_tiles(void);
  * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */
 int hawq_conv2d_band_tile(const hawq_conv_args *args);
 
+/* Fused launch of two consecutive layers of the bottleneck graph (q_resnet.py:231-260): the 1x1 expand conv of unit i
+ * with its RESIDUAL epilogue (x + identity -> quant_act_int32 -> ReLU -> quant_act of unit i+1) and the 1x1 reduce
+ * conv of unit i+1 with its REQUANT epilogue (ReLU -> quant_act1).  `expand` and `reduce` are filled exactly as for
+ * two hawq_conv2d calls, except that expand.out_q and reduce.in are ignored: the 8-bit block input of unit i+1 stays
+ * on chip.  Needs: both convs 1x1 / stride 1, int8 operands, fast_tables != 0, uint16 residual in and out (single
+ * branch), reduce.Cin == expand.Cout, reduce.Cout == expand.Cin in {64, 128, 256}, 8-bit outputs.
+ * tile: 0 = default kernel variant for the channel count, 1..hawq_conv_expand_reduce_variants() = a specific one. */
+typedef struct hawq_expand_reduce_args {
+    hawq_conv_args expand;
+    hawq_conv_args reduce;
+    int32_t tile;
+} hawq_expand_reduce_args;
+int hawq_conv_expand_reduce(const hawq_expand_reduce_args *args, void *stream);
+/* number of kernel variants that take this pair (0: the pair cannot be fused, launch two hawq_conv2d instead) */
+int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *args);
+
 /* QuantAct input case (quant_modules.py:271-274; quant_utils.py:73-97, 237-258):
  * q = clamp(rint(inv_scale * x), lo, hi); fp32 NCHW [N][3][H][W] -> int8 NHWC4 with a zero
  * border: out[N][H+2*pad_t..][..][4]; out_h/out_w are the padded extents, (pad_top, pad_left)

