@@ -180,21 +180,41 @@ def write_per_op(path, ops, rows, batch):
         f.write("\n".join(lines) + "\n")
 
 
+class _stdout_to_stderr:
+    """RCCL prints its version banner on STDOUT at init; this script's stdout is ONE JSON line.  Route fd 1 to fd 2
+    while the collective library may print (C stdio is flushed before the descriptor is restored)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._libc = C.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def rccl_world1_selfcheck(dev, logits):
     """Run the gather path (hawq_amd.dist.gather_logits -> all_gather_into_tensor) once through RCCL in a world of ONE
     rank, so that the collective code has executed on this GPU even in the N = 1 bench run.  Outside the timed region."""
     import socket
     import torch.distributed as dist
     try:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-        out = torch.empty_like(logits)
-        dist.all_gather_into_tensor(out, logits.contiguous())
-        torch.cuda.synchronize()
-        ok = bool(torch.equal(out, logits))
-        dist.destroy_process_group()
+        with _stdout_to_stderr():
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            out = torch.empty_like(logits)
+            dist.all_gather_into_tensor(out, logits.contiguous())
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(out, logits))
+            dist.destroy_process_group()
         return ok
     except Exception as exc:  # never let a rendezvous problem take the bench line down
         return f"failed: {type(exc).__name__}: {exc}"
@@ -226,7 +246,11 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)   # communicator set-up (and RCCL's banner) happens at the first collective
+            torch.cuda.synchronize()
 
     from hawq_amd import roofline
     from hawq_amd.dist import shard_bounds
@@ -276,7 +300,9 @@ def main():
                        "residual_uint16_overflow": overflow,
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "exact_tie_requant_launches": eng.n_tie,
                        "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
-                       "fused_expand_reduce_launches": len(eng.er_choice), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
+                       # candidate expand->reduce pairs: variant id of the fused launch, 0 = two separate launches were faster
+                       "fused_expand_reduce_launches": sum(1 for v in eng.er_choice.values() if v), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
+                       "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(eng, "er_split_tiles", {}).values()),
                        "concurrent_sub_batches": eng.chains},
             # all logits of this rank's images against the CPU oracle's golden logits of the same workload
             "parity": {"gpu_logits_bit_equal_oracle": parity, "images_compared": local_batch if parity is not None else 0,
@@ -366,11 +392,12 @@ def main():
                 del m2, e2, x2
                 torch.cuda.empty_cache()
         out["extra"] = extra
+    if world > 1:
+        with _stdout_to_stderr():
+            dist.barrier()
+            dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -35,33 +35,46 @@ struct ERP {
     int y_lo, y_hi;                    // clamp of the reduce conv's QuantAct (ReLU folded into y_lo)
     int y_planar;
     int32_t *flags;
+    long long *dbgbuf;   // HAWQ_DBG=128: per-phase cycle sums of wave 0 of workgroup 8 (timing experiments only)
 };
 
 __device__ __attribute__((aligned(16))) const int g_er_zero16[4] = {0, 0, 0, 0};
 
 // C: channels of the expand conv's input = of the reduce conv's output.  WM: pixel MFMA tiles (32 pixels) per
-// workgroup = waves along the pixel axis; 2 waves along the channel axis.  NSW: weight ring stages.
-template <int C_, int WM_, int MINB_>
+// workgroup = compute waves along the pixel axis (x 2 along the channel axis).  NP: producer waves that own every
+// LDS-DMA instruction (0: the compute waves issue them themselves).  An LDS-DMA instruction costs its wave 180-330
+// cycles (HAWQ_DBG=128 stamps, profiles/r02_fused_er_steps.md) - the per-wave ingest cap of tools/ubench/ingest_shape.hip
+// seen from inside - so the ingest rate of a CU is set by HOW MANY waves issue, and producers only pay when they add
+// issuing waves without costing compute occupancy (they get the same register allocation as the compute waves).
+// RESDMA: the old residual slice is prefetched one slice ahead into LDS by the producers (memory-bound stage 1: the
+// HBM latency needs a whole slice of cover); otherwise each compute lane loads its 32 bytes straight into registers at
+// the top of the slice (L2 / Infinity-Cache resident in the later stages; 16 KiB less LDS, more workgroups per CU).
+template <int C_, int WM_, int NP_, bool RESDMA_, int MINB_>
 struct ERCfg {
-    static constexpr int C = C_, WM = WM_, MINB = MINB_;
-    static constexpr int BM = 32 * WM, NW = 2 * WM, NT = 64 * NW;
+    static constexpr int C = C_, WM = WM_, NP = NP_, MINB = MINB_;
+    static constexpr bool RESDMA = RESDMA_;
+    static constexpr int BM = 32 * WM, NW = 2 * WM, NTC = 64 * NW, NT = NTC + 64 * NP;
+    static constexpr int NI = NP > 0 ? NP : NW, NPT = 64 * NI;   // waves / threads that issue LDS-DMA (NP == 0: the compute waves themselves)
     static constexpr int KC = C / 64;          // 64-byte chunks of GEMM1's K
     static constexpr int CT2 = C / 64;         // 32-channel MFMA tiles per wave in GEMM2 (2 waves across the C channels)
-    static constexpr int RPP = NT / 4;         // operand rows per LDS-DMA pass (4 lanes x 16 B per 64-byte row)
+    static constexpr int RPP = NPT / 4;        // operand rows per producer LDS-DMA pass (4 lanes x 16 B per 64-byte row)
     static constexpr int NSW = 3;
     static constexpr int WSTAGE = 64 * C;      // W3 slice [KC][64 rows][64 B]  ==  W1 slice [C rows][64 B]
-    static constexpr int WPASS = WSTAGE / (RPP * 64);   // LDS-DMA instructions per thread per ring stage
+    static constexpr int WPASS = WSTAGE / (RPP * 64);   // LDS-DMA instructions per producer thread per ring stage
+    static constexpr int XPASS = BM / RPP;     // per 64-byte chunk of the x2 tile
+    static constexpr int RPASS = BM * 8 / NPT; // residual slice: BM rows x 8 chunks of 16 B
     static constexpr int X2_BYTES = BM * C;
     static constexpr int Q_BYTES = BM * 64, RES_BYTES = BM * 128;
-    // LDS map
+    // LDS map.  q is single-buffered: written between B1(j) and B2(j), read between B2(j) and B1(j+1); so is the residual
+    // staging tile unless it doubles as the prefetch target (RESDMA: in place, two buffers)
     static constexpr int OFF_X2 = 0;
     static constexpr int OFF_RING = OFF_X2 + X2_BYTES;
-    static constexpr int OFF_Q = OFF_RING + NSW * WSTAGE;       // [2][BM][64 B]
-    static constexpr int OFF_RES = OFF_Q + 2 * Q_BYTES;         // [2][BM][64] uint16
-    static constexpr int OFF_CT3 = OFF_RES + 2 * RES_BYTES;     // [2][64][16 B]
-    static constexpr int OFF_CT1 = OFF_CT3 + 2 * 1024;          // [C][16 B]
-    static constexpr int LDS_BYTES = OFF_CT1 + C * 16;
-    static_assert(WSTAGE % (RPP * 64) == 0 && BM == RPP, "tile rows must fill whole LDS-DMA passes");
+    static constexpr int OFF_Q = OFF_RING + NSW * WSTAGE;       // [BM][64 B]
+    static constexpr int OFF_RES = OFF_Q + Q_BYTES;             // [1 or 2][BM][64] uint16
+    static constexpr int OFF_CT3 = OFF_RES + (RESDMA ? 2 : 1) * RES_BYTES;   // [2][64][16 B]
+    static constexpr int LDS_BYTES = OFF_CT3 + 2 * 1024;
+    static_assert(WSTAGE % (RPP * 64) == 0 && BM % RPP == 0 && (BM * 8) % NPT == 0 && C % RPP == 0 && (RPP & 15) == 0,
+                  "tiles must fill whole producer passes");
     static_assert(BM * C <= NSW * WSTAGE, "the output tile is staged on the weight ring");
 };
 
@@ -71,8 +84,8 @@ __device__ __forceinline__ void dma16(const char *src, char *dst) {
 __device__ __forceinline__ void dma4(const char *src, char *dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
 }
-__device__ __forceinline__ DyNt ctab_entry(const char *ctab_lds, int ch) {
-    const v4i t = *reinterpret_cast<const v4i *>(ctab_lds + ch * 16);
+__device__ __forceinline__ DyNt ctab_entry(const char *ctab, int ch) {
+    const v4i t = *reinterpret_cast<const v4i *>(ctab + ch * 16);
     DyNt d;
     d.m = t.x, d.s = t.y & 0xff, d.k = t.y >> 8;
     d.add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
@@ -84,84 +97,129 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MODE = TIE ? 2 : 0;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wave_m = wave % F::WM, wave_c = wave / F::WM;   // GEMM1: 32 px x 32 ch per wave; GEMM2: 32 px x C/2 ch
-    const int l31 = lane & 31, h = lane >> 5;
-    const int lrow = t >> 2, lslot = t & 3;
+    const bool producer = F::NP > 0 && wave >= F::NW;
     const int m0 = blockIdx.x * F::BM;
     const int nslices = p.C3 >> 6;
-    const char *zero = reinterpret_cast<const char *>(g_er_zero16);
     char *x2t = smem + F::OFF_X2, *ring = smem + F::OFF_RING, *qt = smem + F::OFF_Q, *rest = smem + F::OFF_RES;
-    char *ct3 = smem + F::OFF_CT3, *ct1 = smem + F::OFF_CT1;
-
-    // ---------------------------------------------------------------- LDS-DMA issue helpers (all waves, uniform counts)
-    const int sw = (lslot ^ ((lrow >> 2) & 3)) << 4;   // source-side swizzle of this thread's 16-byte slot (rows lrow + k * RPP: same)
-    static_assert((F::RPP & 15) == 0, "the swizzle of row r + RPP equals that of row r");
+    char *ct3 = smem + F::OFF_CT3;
+    const bool prof = p.dbgbuf != nullptr;
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define ER_STAMP(K)                                                    \
+    if (prof) {                                                        \
+        const long long now = (long long)__builtin_readcyclecounter(); \
+        ph[K] += now - tprev;                                          \
+        tprev = now;                                                   \
+    }
+    // Ring stage of W3(j) is (2j) % 3, of W1(j) is (2j + 1) % 3.  Two barriers per slice:
+    //   B1(j): W3(j), ctab3(j) (and residual(j)) have landed; every wave is done with slice j-1
+    //   B2(j): W1(j) has landed; q(j) and the new residual slice are written; GEMM1(j) has released W3(j)'s stage
+    // ---------------------------------------------------------------- LDS-DMA issue (producer waves, or every compute wave)
+    const int pt = F::NP > 0 ? t - F::NTC : t, pw = F::NP > 0 ? wave - F::NW : wave;   // index among the issuing threads / waves
+    const int prow = pt >> 2, pslot = pt & 3;
+    const int sw = (pslot ^ ((prow >> 2) & 3)) << 4;   // source-side swizzle of this thread's 16-byte slot (same for rows prow + k * RPP)
+    const char *zero = reinterpret_cast<const char *>(g_er_zero16);
     auto issue_w3 = [&](int j, int stage) {   // rows j*64 .. j*64+63 of W3 [C3][C], as KC chunks of [64 rows][64 B]
-        char *dst = ring + stage * F::WSTAGE + wave * 1024;
+        char *dst = ring + stage * F::WSTAGE + pw * 1024;
 #pragma unroll
         for (int i = 0; i < F::WPASS; ++i) {
-            const int idx = i * F::RPP + lrow, chunk = idx >> 6, row = idx & 63;
+            const int idx = i * F::RPP + prow, chunk = idx >> 6, row = idx & 63;
             dma16((const char *)p.w3 + (size_t)(j * 64 + row) * F::C + chunk * 64 + sw, dst + i * (F::RPP * 64));
         }
     };
     auto issue_w1 = [&](int j, int stage) {   // columns j*64 .. j*64+63 of W1 [C][C3], as [C rows][64 B]
-        char *dst = ring + stage * F::WSTAGE + wave * 1024;
+        char *dst = ring + stage * F::WSTAGE + pw * 1024;
 #pragma unroll
         for (int i = 0; i < F::WPASS; ++i) {
-            const int row = i * F::RPP + lrow;
+            const int row = i * F::RPP + prow;
             dma16((const char *)p.w1 + (size_t)row * p.C3 + j * 64 + sw, dst + i * (F::RPP * 64));
         }
     };
-    auto issue_res = [&](int j) {   // residual slice [BM][64] uint16, 16-byte chunks swizzled by the pixel row; + ctab3 slice
-        char *dst = rest + (j & 1) * F::RES_BYTES;
+    auto issue_grp = [&](int j) {   // ctab3 slice: 4 x 256 B (issuing waves beyond the 4th repeat); residual slice if RESDMA
+        dma4((const char *)p.ctab3 + (size_t)j * 1024 + (pw & 3) * 256 + lane * 4, ct3 + (j & 1) * 1024 + (pw & 3) * 256);
+        if constexpr (F::RESDMA) {
+            char *dst = rest + (j & 1) * F::RES_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int base = (i * F::NW + wave) * 64, idx = base + lane;
-            const int row = idx >> 3, jj = idx & 7;
-            const int grow = (m0 + row < p.M) ? m0 + row : m0;
-            dma16((const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
+            for (int i = 0; i < F::RPASS; ++i) {
+                const int base = (i * F::NI + pw) * 64, idx = base + lane;
+                const int row = idx >> 3, jj = idx & 7;
+                const int grow = (m0 + row < p.M) ? m0 + row : m0;
+                dma16((const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
+            }
         }
-        dma4((const char *)p.ctab3 + (size_t)j * 1024 + (wave & 3) * 256 + lane * 4, ct3 + (j & 1) * 1024 + (wave & 3) * 256);
     };
-    constexpr int N_A = F::WPASS + 3;   // loads per thread of one {W3, residual, ctab3} group
-
-    // ---------------------------------------------------------------- prologue
-    {   // resident x2 tile: KC chunks of [BM pixel rows][64 B]
-        const bool v = m0 + lrow < p.M;
+    auto issue_prologue = [&]() {
 #pragma unroll
-        for (int kc = 0; kc < F::KC; ++kc)
-            dma16(v ? (const char *)p.x2 + (size_t)(m0 + lrow) * F::C + kc * 64 + sw : zero, x2t + kc * (F::BM * 64) + wave * 1024);
-        // ctab of the reduce conv: C entries of 16 B = C / 64 wave pieces (the waves' load counts may differ here: every
-        // counted wait below only ever leaves a wave's YOUNGEST loads in flight, which are the same for all waves)
-        for (int pc = wave; pc < F::C / 64; pc += F::NW)
-            dma16((const char *)p.ctab1 + (size_t)(pc * 64 + lane) * 16, ct1 + pc * 1024);
+        for (int kc = 0; kc < F::KC; ++kc)   // resident x2 tile: KC chunks of [BM pixel rows][64 B]
+#pragma unroll
+            for (int i = 0; i < F::XPASS; ++i) {
+                const int row = i * F::RPP + prow;
+                dma16(m0 + row < p.M ? (const char *)p.x2 + (size_t)(m0 + row) * F::C + kc * 64 + sw : zero,
+                      x2t + kc * (F::BM * 64) + i * (F::RPP * 64) + pw * 1024);
+            }
+        issue_w3(0, 0);
+        issue_grp(0);
+        issue_w1(0, 1);
+        wait_vmcnt<F::WPASS>();   // everything but W1(0) has landed
+    };
+    constexpr int N_A = F::WPASS + 1 + (F::RESDMA ? F::RPASS : 0);   // instructions per thread of one {W3, ctab3, residual} group
+    if (F::NP > 0 && producer) {
+        // ------------------------------------------------------------ producer waves: all LDS-DMA, nothing else
+        issue_prologue();
+        for (int j = 0; j < nslices; ++j) {
+            __builtin_amdgcn_s_barrier();   // B1(j)
+            if (j + 1 < nslices) {
+                issue_w3(j + 1, (2 * j + 2) % 3);   // the stage GEMM2(j-1) read
+                issue_grp(j + 1);
+                wait_vmcnt<N_A>();                  // W1(j) is older than this group
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();   // B2(j)
+            if (j + 1 < nslices) {
+                issue_w1(j + 1, (2 * j + 3) % 3);   // the stage GEMM1(j) read
+                wait_vmcnt<F::WPASS>();             // the {W3, ctab3, residual}(j+1) group has landed (no stores here: counts are exact)
+            }
+        }
+        __syncthreads();
+        __syncthreads();
+        return;
     }
-    issue_w3(0, 0);
-    issue_res(0);
-    issue_w1(0, 1);
-
+    // ---------------------------------------------------------------- compute waves
+    const int wave_m = wave % F::WM, wave_c = wave / F::WM;   // GEMM1: 32 px x 32 ch per wave; GEMM2: 32 px x C/2 ch
+    const int l31 = lane & 31, h = lane >> 5;
     v16i acc2[F::CT2];
 #pragma unroll
     for (int c = 0; c < F::CT2; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
-
     const int arow = wave_m * 32 + l31;                           // this lane's pixel row (both GEMMs, both epilogues)
     const int wrow1 = wave_c * 32 + cperm(l31);                   // GEMM1: W3 slice row
     const int lch = wave_c * 32 + h * 16;                         // slice-local first channel of this lane's 16 outputs
     const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
     const unsigned rowmask = (m0 + arow < p.M) ? 0xffffffffu : 0u;
+    const int res_row = (m0 + arow < p.M) ? m0 + arow : m0;       // rows beyond M read a valid row and are never stored
     unsigned oor = 0;
-
-    wait_vmcnt<F::WPASS>();   // everything but W1(0) has landed
-    // ring stage of W3(j) is (2j) % 3, of W1(j) is (2j + 1) % 3
+    if constexpr (F::NP == 0) issue_prologue();
+    ER_STAMP(0)
     for (int j = 0; j < nslices; ++j) {
         const int st3 = (2 * j) % 3, st1 = (2 * j + 1) % 3;
-        __builtin_amdgcn_s_barrier();   // B1(j): W3(j), residual(j), ctab3(j) visible; GEMM2(j-1) reads and its stores' LDS reads done
-        if (j + 1 < nslices) {
-            issue_w3(j + 1, (2 * j + 2) % 3);
-            issue_res(j + 1);
+        __builtin_amdgcn_s_barrier();   // B1(j)
+        ER_STAMP(1)
+        // !RESDMA: this lane's 16 residual values of slice j (32 contiguous bytes) straight into registers.  Hand-issued
+        // and waited for (the only younger memory operations of a compute wave are none; its stores are older)
+        v4i rin[2];
+        if constexpr (!F::RESDMA) {
+            const char *rp = (const char *)p.res_in + ((size_t)res_row * p.C3 + j * 64 + lch) * 2;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rin[0]) : "v"(rp) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rin[1]) : "v"(rp) : "memory");
         }
+        if constexpr (F::NP == 0)   // after the residual loads: the counted wait in front of the epilogue leaves this group in flight
+            if (j + 1 < nslices) {
+                issue_w3(j + 1, (2 * j + 2) % 3);
+                issue_grp(j + 1);
+            }
+        ER_STAMP(2)
         // ------------------------------------------------------------ GEMM1
         v16i acc1;
 #pragma unroll
@@ -177,13 +235,19 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                     acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc1, 0, 0, 0);
                 }
         }
+        ER_STAMP(3)
         // ------------------------------------------------------------ epilogue 1: residual add, ReLU, next QuantAct
         {
-            char *rb = rest + (j & 1) * F::RES_BYTES + arow * 128;
+            char *rb = rest + (F::RESDMA ? (j & 1) * F::RES_BYTES : 0) + arow * 128;
             const char *ctb = ct3 + (j & 1) * 1024;
-            v4i rin[2];
-            rin[0] = *reinterpret_cast<const v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4));
-            rin[1] = *reinterpret_cast<const v4i *>(rb + ((((lch >> 3) + 1) ^ (arow & 7)) << 4));
+            if constexpr (F::RESDMA) {
+                rin[0] = *reinterpret_cast<const v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4));
+                rin[1] = *reinterpret_cast<const v4i *>(rb + ((((lch >> 3) + 1) ^ (arow & 7)) << 4));
+            } else {
+                // older than the residual loads: W1(j), the stores of slice j-1; younger: only the DMA group (NP == 0)
+                if (F::NP == 0 && j + 1 < nslices) wait_vmcnt<N_A>(); else wait_vmcnt<0>();
+                asm volatile("" : "+v"(rin[0]), "+v"(rin[1]));
+            }
             int rpack[8], qpack[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -207,17 +271,20 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
             *reinterpret_cast<v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4)) = ra;
             *reinterpret_cast<v4i *>(rb + ((((lch >> 3) + 1) ^ (arow & 7)) << 4)) = rc;
             const v4i qw = {qpack[0], qpack[1], qpack[2], qpack[3]};
-            *reinterpret_cast<v4i *>(qt + (j & 1) * F::Q_BYTES + lds_off(arow, lch >> 4)) = qw;
+            *reinterpret_cast<v4i *>(qt + lds_off(arow, lch >> 4)) = qw;
         }
-        // W1(j) was issued before this slice's {W3, residual, ctab3}(j+1) group: wait for it, leave the group in flight
-        if (j + 1 < nslices) wait_vmcnt<N_A>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // B2(j): q(j) and the new residual slice visible, W1(j) visible, GEMM1(j) reads done
+        ER_STAMP(4)
+        if constexpr (F::NP == 0 && F::RESDMA) {   // W1(j) is older than this slice's group
+            if (j + 1 < nslices) wait_vmcnt<N_A>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();   // B2(j)
+        ER_STAMP(5)
         // ------------------------------------------------------------ GEMM2 partial sum over this slice's 64 channels
         {
-            const char *w1s = ring + st1 * F::WSTAGE, *qs = qt + (j & 1) * F::Q_BYTES;
+            const char *w1s = ring + st1 * F::WSTAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const v4i af = *reinterpret_cast<const v4i *>(qs + lds_off(arow, 2 * ks + h));
+                const v4i af = *reinterpret_cast<const v4i *>(qt + lds_off(arow, 2 * ks + h));
 #pragma unroll
                 for (int c = 0; c < F::CT2; ++c) {
                     const v4i wf = *reinterpret_cast<const v4i *>(w1s + lds_off(wave_c * (F::CT2 * 32) + c * 32 + cperm(l31), 2 * ks + h));
@@ -225,21 +292,27 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 }
             }
         }
+        ER_STAMP(6)
         // Stores count on vmcnt like loads and may retire before OLDER loads: every load that a later counted wait
-        // targets must have landed before a store is issued.  {W3, residual, ctab3}(j+1) had GEMM1 + epilogue + GEMM2.
-        wait_vmcnt<0>();
+        // targets must have landed before a store is issued ({W3, ctab3, residual}(j+1) had the whole slice)
+        if constexpr (F::NP == 0) wait_vmcnt<0>();
         {   // new residual slice -> memory, whole 128-byte rows
-            const char *src = rest + (j & 1) * F::RES_BYTES;
+            const char *src = rest + (F::RESDMA ? (j & 1) * F::RES_BYTES : 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = t + F::NT * i, row = idx >> 3, jj = idx & 7;
+            for (int i = 0; i < F::BM * 8 / F::NTC; ++i) {
+                const int idx = t + F::NTC * i, row = idx >> 3, jj = idx & 7;
                 if (m0 + row < p.M)
                     *reinterpret_cast<v4i *>((char *)p.res_out + ((size_t)(m0 + row) * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4)) =
                         *reinterpret_cast<const v4i *>(src + idx * 16);
             }
         }
-        if (j + 1 < nslices) issue_w1(j + 1, (2 * j + 3) % 3);   // into the stage GEMM1(j) read (all waves are past B2(j))
+        if constexpr (F::NP == 0)
+            if (j + 1 < nslices) issue_w1(j + 1, (2 * j + 3) % 3);   // into the stage GEMM1(j) read (all waves are past B2(j))
+        ER_STAMP(7)
     }
+    if (prof && blockIdx.x == 8 && t == 0)
+        for (int k = 0; k < 8; ++k) p.dbgbuf[k] = ph[k];
+#undef ER_STAMP
     if ((oor >> 16) != 0) atomicOr(p.flags, 1);
     // ---------------------------------------------------------------- epilogue 2: the reduce conv's QuantAct
     __syncthreads();   // all GEMM2 fragment reads done: the ring becomes the output staging tile [BM][C B]
@@ -255,7 +328,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 int qv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    qv[k] = med3i(dyadic_mode<MODE>(acc2[c][4 * g + k], ctab_entry(ct1, ch0 + 4 * g + k)), p.y_lo, p.y_hi);
+                    qv[k] = med3i(dyadic_mode<MODE>(acc2[c][4 * g + k], ctab_entry((const char *)p.ctab1, ch0 + 4 * g + k)), p.y_lo, p.y_hi);
                 w[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
             }
             const v4i ww = {w[0], w[1], w[2], w[3]};
@@ -264,16 +337,16 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
         __syncthreads();
         if (p.y_planar) {   // channel-group planes [C / 16][M][16 B] (hawq_conv_args.out_planar)
 #pragma unroll
-            for (int i = 0; i < F::BM * CPR / F::NT; ++i) {
-                const int idx = t + F::NT * i, ch = idx / F::BM, row = idx % F::BM;
+            for (int i = 0; i < F::BM * CPR / F::NTC; ++i) {
+                const int idx = t + F::NTC * i, ch = idx / F::BM, row = idx % F::BM;
                 if (m0 + row < p.M)
                     *reinterpret_cast<v4i *>((char *)p.y + ((size_t)ch * p.M + (m0 + row)) * 16) =
                         *reinterpret_cast<const v4i *>(yt + (row * CPR + (ch ^ (row & (CPR - 1)))) * 16);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < F::BM * CPR / F::NT; ++i) {
-                const int idx = t + F::NT * i, row = idx / CPR, jj = idx % CPR;
+            for (int i = 0; i < F::BM * CPR / F::NTC; ++i) {
+                const int idx = t + F::NTC * i, row = idx / CPR, jj = idx % CPR;
                 if (m0 + row < p.M)
                     *reinterpret_cast<v4i *>((char *)p.y + (size_t)(m0 + row) * F::C + ((jj ^ (row & (CPR - 1))) << 4)) =
                         *reinterpret_cast<const v4i *>(yt + idx * 16);
@@ -282,16 +355,20 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
     }
 }
 
-using E64 = ERCfg<64, 2, 3>;      // stage 1: 64 pixels, 4 waves, 43 KiB of LDS -> 3 workgroups per CU
-using E128 = ERCfg<128, 2, 2>;    // stage 2: 64 pixels, 4 waves, 62 KiB
-using E128W = ERCfg<128, 4, 1>;   // stage 2: 128 pixels, 8 waves (the weight slices are streamed once per 128 pixels)
-using E256 = ERCfg<256, 4, 1>;    // stage 3: 128 pixels, 8 waves, 134 KiB
-constexpr int NUM_ER = 4;
+// MINB = waves per SIMD the register allocation must allow (launch_bounds)
+using E64 = ERCfg<64, 2, 0, true, 4>;       // stage 1: 64 pixels, 4 waves, 38 KiB of LDS -> 4 workgroups per CU; residual prefetched into LDS
+using E64R = ERCfg<64, 2, 0, false, 4>;     //          residual through registers, 30 KiB
+using E128 = ERCfg<128, 2, 0, false, 3>;    // stage 2: 64 pixels, 4 waves, 46 KiB -> 3 workgroups per CU
+using E128D = ERCfg<128, 2, 0, true, 3>;    //          residual prefetched into LDS, 54 KiB
+using E128P = ERCfg<128, 2, 4, true, 4>;    //          4 + 4 waves (producers own the LDS-DMA), two workgroups per CU
+using E256 = ERCfg<256, 4, 0, false, 2>;    // stage 3: 128 pixels, 8 waves, 106 KiB, one workgroup per CU
+using E256P = ERCfg<256, 4, 4, true, 3>;    //          8 + 4 waves, residual prefetched into LDS, 122 KiB
+constexpr int NUM_ER = 7;
 
 typedef void (*ERFn)(const ERP);
 struct ERInfo { ERFn fn[2]; int c, bm, nt, lds; };
 #define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>}, F::C, F::BM, F::NT, F::LDS_BYTES}
-const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E128), ER_ENTRY(E128W), ER_ENTRY(E256)};
+const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P)};
 
 bool conv_is_1x1_int8_fast(const hawq_conv_args &a) {
     return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 && !a.in2 &&
@@ -348,6 +425,10 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     p.y_lo = r.relu && r.q_lo < 0 ? 0 : r.q_lo, p.y_hi = r.q_hi;
     p.y_planar = r.out_planar;
     p.flags = e.flags;
+    static const int dbg_env = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
+    static long long *dbg_dev = nullptr;
+    if ((dbg_env & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
+    p.dbgbuf = (dbg_env & 128) ? dbg_dev : nullptr;
     const ERInfo &ei = kER[v];
     static const bool attrs = [] {
         bool good = true;
@@ -360,5 +441,13 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     const bool tie = ((e.fast_tables | r.fast_tables) & 4) != 0;
     hipLaunchKernelGGL(ei.fn[tie ? 1 : 0], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
+    if (p.dbgbuf) {  // experiment hook (synchronises!)
+        long long hb[8];
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipMemcpy(hb, p.dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[expand-reduce C=%d bm=%d M=%d C3=%d] cycles of wave 0 / workgroup 8: prologue %lld | B1 wait %lld | issue W3+res %lld | GEMM1 %lld | "
+                        "epilogue1 %lld | W1 wait + B2 %lld | GEMM2 %lld | vmcnt0 + stores + issue W1 %lld\n",
+                ei.c, ei.bm, p.M, p.C3, hb[0], hb[1], hb[2], hb[3], hb[4], hb[5], hb[6], hb[7]);
+    }
     return 0;
 }

@@ -64,6 +64,23 @@ class _OpList(list):
         super().append(fn)
 
 
+class _FusedPair:
+    """One entry of the launch list that covers TWO layers - the expand conv (+ residual epilogue) of unit i and the reduce
+    conv of unit i+1 - either as one hawq_conv_expand_reduce launch or as two hawq_conv2d launches, whichever the
+    autotuner measured faster for this batch shape (results are identical)."""
+
+    def __init__(self, er, expand, reduce, stream):
+        self.er, self.expand, self.reduce, self.sp = er, expand, reduce, stream
+        self.fused = True
+
+    def __call__(self):
+        if self.fused:
+            _lib.call("hawq_conv_expand_reduce", C.byref(self.er), self.sp)
+        else:
+            _lib.call("hawq_conv2d", C.byref(self.expand), self.sp)
+            _lib.call("hawq_conv2d", C.byref(self.reduce), self.sp)
+
+
 class _Conv:
     """Device-resident parameters of one QuantBnConv2d."""
 
@@ -322,8 +339,15 @@ class IntegerEngine:
         r.out_q = out.data_ptr()
         planar = self.planar and self._band_takes(nxt['convs'][1], N, ho, wo, 8, False, nxt)
         r.out_planar = int(planar)
-        keep += [out, er]
-        return er, out, 8, planar
+        # the same two layers as separate launches (the block input q then goes through memory)
+        q = self._alloc(N * ho * wo * c.cin, torch.uint8)
+        a.out_q = q.data_ptr()
+        r1 = _lib.ConvArgs()
+        C.memmove(C.byref(r1), C.byref(r), C.sizeof(r1))
+        r1.in_ = q.data_ptr()
+        pair = _FusedPair(er, a, r1, self.stream.cuda_stream)
+        keep += [out, er, q, r1, pair]
+        return pair, out, 8, planar
 
     def _alloc(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.dev)
@@ -389,6 +413,7 @@ class IntegerEngine:
             self.n_fast, self.n_conv, self.n_k0, self.n_tie = (self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0,
                                                               self.subs[0].n_tie)
             self.tile_choice, self.er_choice = self.subs[0].tile_choice, self.subs[0].er_choice
+            self.er_split_tiles = getattr(self.subs[0], "er_split_tiles", {})
             return
         self.subs = []
         ops, keep = _OpList(), []
@@ -517,12 +542,12 @@ class IntegerEngine:
                     a.out_q = new_qa.data_ptr()
                     keep.append(new_qa)
                 if fz is not None:
-                    er, fout, fbits, fplanar = fz
+                    pair, fout, fbits, fplanar = fz
                     fused_in = (fout, fbits, fplanar)
-                    self._er_args.append(er)
+                    self._er_args.append(pair)
                     self._er_names.append(tap_name)
                     ops.next_name = tap_name + "+" + nxt['name'] + ".quant_convbn1"
-                    ops.append(partial(_lib.call, "hawq_conv_expand_reduce", C.byref(er), sp))
+                    ops.append(pair)
                     continue
                 self._conv_args.append(a)
                 self._conv_names.append(tap_name)
@@ -603,9 +628,13 @@ class IntegerEngine:
             for name, a, tid in zip(self._conv_names, self._conv_args, ids):
                 a.tile = tid
                 self.tile_choice[name] = tid
-            for k, (name, er) in enumerate(zip(self._er_names, self._er_args)):
-                er.tile = int(os.environ.get("HAWQ_ER_TILES", "0." * len(self._er_args)).split(".")[k] or 0)
-                self.er_choice[name] = er.tile
+            for k, (name, pair) in enumerate(zip(self._er_names, self._er_args)):
+                v = os.environ.get("HAWQ_ER_TILES", ".".join(["1"] * len(self._er_args))).split(".")[k]
+                pair.er.tile = int(v)
+                pair.fused = pair.er.tile != 0
+                if not pair.fused:
+                    pair.expand.tile, pair.reduce.tile = (int(x) for x in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
+                self.er_choice[name] = pair.er.tile
             return
         with torch.cuda.stream(self.stream):
             self._launch_all()  # every buffer holds valid data
@@ -634,10 +663,34 @@ class IntegerEngine:
                     print(f"[autotune N={a.N}] {name}: best {best_t}  us per tile: {' '.join(log)}", file=sys.stderr)
                 a.tile = best_t
                 self.tile_choice[name] = best_t
-            fixed_er = os.environ.get("HAWQ_ER_TILES")
-            for k, (name, er) in enumerate(zip(self._er_names, self._er_args)):
+            def best_tile(a):   # fastest applicable tile of one hawq_conv2d launch: (tile, ms per `reps` launches)
+                times = {}
+                for rnd in range(2):
+                    for tile in range(1, n_tiles + 1):
+                        if rnd and tile not in times:
+                            continue
+                        a.tile = tile
+                        try:
+                            _lib.call("hawq_conv2d", C.byref(a), sp)
+                            _lib.call("hawq_event_record", e0, sp)
+                            for _ in range(reps):
+                                _lib.call("hawq_conv2d", C.byref(a), sp)
+                            _lib.call("hawq_event_record", e1, sp)
+                            _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
+                        except RuntimeError:
+                            continue
+                        times[tile] = min(times.get(tile, ms.value), ms.value)
+                t = min(times, key=times.get)
+                return t, times[t]
+
+            fixed_er = os.environ.get("HAWQ_ER_TILES")   # dotted list as printed by bench.py; 0 = two separate launches
+            for k, (name, pair) in enumerate(zip(self._er_names, self._er_args)):
+                er = pair.er
                 if fixed_er:
                     er.tile = int(fixed_er.split(".")[k])
+                    pair.fused = er.tile != 0
+                    if not pair.fused:
+                        pair.expand.tile, pair.reduce.tile = (int(v) for v in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
                     self.er_choice[name] = er.tile
                     continue
                 nvar = _lib.load().hawq_conv_expand_reduce_variants(C.byref(er))
@@ -653,10 +706,18 @@ class IntegerEngine:
                         _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
                         times[tile] = min(times.get(tile, ms.value), ms.value)
                 er.tile = min(times, key=times.get)
+                te, ms_e = best_tile(pair.expand)
+                tr, ms_r = best_tile(pair.reduce)
+                pair.expand.tile, pair.reduce.tile = te, tr
+                pair.fused = times[er.tile] <= ms_e + ms_r
                 if os.environ.get("HAWQ_AUTOTUNE_LOG"):
                     log = [f"{t}:{v / reps * 1e3:.1f}" for t, v in times.items()]
-                    print(f"[autotune N={er.expand.N}] {name}+next reduce (fused): best {er.tile}  us per variant: {' '.join(log)}", file=sys.stderr)
-                self.er_choice[name] = er.tile
+                    print(f"[autotune N={er.expand.N}] {name}+next reduce: fused variants (us) {' '.join(log)} | separate "
+                          f"{ms_e / reps * 1e3:.1f} (tile {te}) + {ms_r / reps * 1e3:.1f} (tile {tr}) -> {'fused' if pair.fused else 'separate'}",
+                          file=sys.stderr)
+                self.er_choice[name] = er.tile if pair.fused else 0
+                self.er_split_tiles = getattr(self, "er_split_tiles", {})
+                self.er_split_tiles[name] = (te, tr)
         _lib.call("hawq_event_destroy", e0)
         _lib.call("hawq_event_destroy", e1)
         torch.cuda.synchronize(self.dev)
