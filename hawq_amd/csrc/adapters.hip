@@ -163,3 +163,55 @@ extern "C" int hawq_avgpool_f32(const float *x, float *y, int32_t NC, int32_t HW
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Grouped / depthwise integer convolution (MobileNetV2's 3x3 depthwise layers, q_mobilenetv2.py; F.conv2d(..., groups)
+// in quant_modules.py:489-494 / 727-736): exact int32 accumulators for the module-compatible path.  One thread per output
+// element; with one input channel per group (depthwise) neighbouring threads read neighbouring bytes of the NHWC input,
+// and 9 MACs per output leave the layer bound by its own bytes.  Not an MFMA shape: K per output is KH*KW*Cin/groups.
+namespace {
+__global__ void grouped_conv_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ wgt, const int32_t *__restrict__ bias,
+                                    int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int groups,
+                                    int Ho, int Wo, int32_t *__restrict__ out) {
+    const long long total = (long long)N * Ho * Wo * Cout;
+    const int cg_in = Cin / groups, cg_out = Cout / groups;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout);
+        const long long m = idx / Cout;
+        const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
+        const int g = co / cg_out;
+        int acc = bias ? bias[co] : 0;
+        const int8_t *wp = wgt + (size_t)co * KH * KW * cg_in;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int iy = oy * stride - pad + kh;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int ix = ox * stride - pad + kw;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const int8_t *ip = in + (((size_t)n * H + iy) * W + ix) * Cin + (size_t)g * cg_in;
+                const int8_t *wq = wp + (kh * KW + kw) * cg_in;
+                for (int ci = 0; ci < cg_in; ++ci) acc += (int)ip[ci] * (int)wq[ci];
+            }
+        }
+        out[idx] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const int32_t *bias, int32_t N, int32_t H, int32_t W,
+                                   int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t groups,
+                                   int32_t *out_acc, void *stream) {
+    HAWQ_REQUIRE(in && wgt && out_acc, "hawq_conv2d_grouped: null pointer");
+    HAWQ_REQUIRE(groups >= 1 && Cin > 0 && Cout > 0 && Cin % groups == 0 && Cout % groups == 0, "hawq_conv2d_grouped: groups=%d must divide Cin=%d and Cout=%d",
+                 groups, Cin, Cout);
+    HAWQ_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0 && N > 0 && H > 0 && W > 0, "hawq_conv2d_grouped: bad geometry");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_conv2d_grouped: empty output");
+    const long long total = (long long)N * Ho * Wo * Cout;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(grouped_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt, bias, N, H, W, Cin, Cout, KH, KW, stride,
+                       pad, groups, Ho, Wo, out_acc);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -25,6 +25,7 @@ from torch.nn import Module, Parameter
 from . import _lib
 from . import packing
 from .quant_utils import (AsymmetricQuantFunction, SymmetricQuantFunction, asymmetric_linear_quantization_params,
+                          device_min_max, get_percentile_min_max,
                           fixedpoint_fn, fold_bn, quantize_bias, quantize_weight_per_channel, requant_table,
                           symmetric_linear_quantization_params)
 
@@ -107,10 +108,14 @@ class QuantAct(Module):
             raise ValueError("unknown quant mode: {}".format(self.quant_mode))
         _require_device(x, "QuantAct")
 
-        if self.running_stat:  # range calibration (quant_modules.py:233-258), min/max only
-            if self.act_percentile != 0:
-                raise NotImplementedError("percentile activation ranges are QAT-only (out of scope)")
-            x_min, x_max = x.data.min(), x.data.max()
+        if self.running_stat:  # range calibration / QAT range tracking (quant_modules.py:233-258) on the device
+            if self.act_percentile == 0:
+                x_min, x_max = device_min_max(x.data)
+            elif self.quant_mode == 'symmetric':
+                x_min, x_max = get_percentile_min_max(x.detach().view(-1), 100 - self.act_percentile, self.act_percentile,
+                                                      output_tensor=True)
+            else:  # 'asymmetric' (post-ReLU, unsigned, no zero point): the lower bound stays 0 (quant_modules.py:241-245)
+                x_min, x_max = get_percentile_min_max(x.detach().view(-1), 0, self.act_percentile, output_tensor=True)
             if self.x_min == self.x_max:
                 self.x_min += x_min
                 self.x_max += x_max
@@ -147,10 +152,13 @@ class _IntConvMixin:
     """Shared device plumbing: fp32 NCHW (int*scale) -> integer conv kernel -> fp32 NCHW."""
 
     def _run_int_conv(self, x, pre_act_scaling_factor, weight_integer, bias_integer, bias_scale, in_bits, stride,
-                      padding):
+                      padding, groups=1):
         N, Cin, H, W = x.shape
         Cout, _, KH, KW = weight_integer.shape
         dev = x.device
+        if groups != 1:
+            return self._run_grouped_conv(x, pre_act_scaling_factor, weight_integer, bias_integer, bias_scale, stride, padding,
+                                          groups)
         key = (weight_integer.data_ptr(), weight_integer._version, bias_integer.data_ptr(), bias_integer._version,
                str(dev), in_bits)
         if getattr(self, "_dev_key", None) != key:
@@ -186,6 +194,32 @@ class _IntConvMixin:
         self.last_accumulators = (acc, (N, Ho, Wo, cout_p))  # int32 NHWC, for parity checks
         return y
 
+
+    def _run_grouped_conv(self, x, pre_act_scaling_factor, weight_integer, bias_integer, bias_scale, stride, padding, groups):
+        """Grouped / depthwise layers (MobileNetV2): int8 NHWC activations, hawq_conv2d_grouped, exact int32 accumulators."""
+        N, Cin, H, W = x.shape
+        Cout, Cg, KH, KW = weight_integer.shape
+        dev = x.device
+        key = ("g", weight_integer.data_ptr(), weight_integer._version, bias_integer.data_ptr(), bias_integer._version, str(dev))
+        if getattr(self, "_dev_key", None) != key:
+            w = weight_integer.detach().cpu().numpy().astype(np.int8).transpose(0, 2, 3, 1)  # [Cout][KH][KW][Cin / groups]
+            self._dev_w = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
+            b = bias_integer.detach().cpu().numpy().astype(np.int64).clip(-2 ** 31, 2 ** 31 - 1).astype(np.int32)
+            self._dev_b = torch.from_numpy(b).to(dev)
+            self._dev_fs = bias_scale.detach().reshape(-1).float().to(dev).contiguous()
+            self._dev_key = key
+        x = x.contiguous().float()
+        s_a = float(pre_act_scaling_factor.detach().reshape(-1)[0].item())
+        xq = torch.empty(N * H * W * Cin, dtype=torch.uint8, device=dev)
+        _lib.call("hawq_f32_nchw_to_q_nhwc", x.data_ptr(), xq.data_ptr(), N, Cin, H, W, Cin, 8, s_a, _stream())
+        Ho = (H + 2 * padding - KH) // stride + 1
+        Wo = (W + 2 * padding - KW) // stride + 1
+        acc = torch.empty(N * Ho * Wo * Cout, dtype=torch.int32, device=dev)
+        _lib.call("hawq_conv2d_grouped", xq.data_ptr(), self._dev_w.data_ptr(), self._dev_b.data_ptr(), N, H, W, Cin, Cout, KH, KW,
+                  stride, padding, groups, acc.data_ptr(), _stream())
+        y = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=dev)
+        _lib.call("hawq_acc_nhwc_to_f32_nchw", acc.data_ptr(), y.data_ptr(), N, Cout, Ho, Wo, Cout, self._dev_fs.data_ptr(), _stream())
+        return y
 
 class QuantBnConv2d(_IntConvMixin, Module):
     """Conv with folded BatchNorm (reference: quant_modules.py:308-494); frozen/folded branch."""
@@ -236,16 +270,14 @@ class QuantBnConv2d(_IntConvMixin, Module):
         s_a = pre_act_scaling_factor.detach().reshape(-1).float().cpu()
         key = (c.weight._version, c.weight.data_ptr(), b.weight._version, b.bias._version,
                b.running_mean._version, b.running_var._version, self.weight_bit, self.bias_bit, self.per_channel,
-               float(s_a[0]))
+               self.weight_percentile, float(s_a[0]))
         if getattr(self, "_prep_key", None) == key:
             return self._prep_bias_scale
-        if self.weight_percentile != 0:
-            raise NotImplementedError("percentile weight ranges are QAT-only (out of scope)")
         if self.quant_mode != 'symmetric':
             raise Exception('For weight, we only support symmetric quantization.')
         dev = c.weight.device
         w_f, b_f = fold_bn(c.weight, b.weight, b.bias, b.running_mean, b.running_var, b.eps, c.bias)
-        w_int, s_w = quantize_weight_per_channel(w_f, self.weight_bit, self.per_channel)
+        w_int, s_w = quantize_weight_per_channel(w_f, self.weight_bit, self.per_channel, self.weight_percentile)
         self.convbn_scaling_factor = s_w.to(dev)
         self.weight_integer = w_int.to(dev)
         if self.quantize_bias:
@@ -274,13 +306,13 @@ class QuantBnConv2d(_IntConvMixin, Module):
             raise NotImplementedError("unfolded-BN training forward (quant_modules.py:417-438) is QAT-only")
         if self.full_precision_flag:
             raise NotImplementedError("full_precision_flag bypasses the integer path (out of scope)")
-        if self.conv.groups != 1 or self.conv.dilation[0] != 1:
-            raise NotImplementedError("grouped/dilated convolutions are outside the ResNet hot path")
+        if self.conv.dilation[0] != 1:
+            raise NotImplementedError("dilated convolutions are outside the path")
         _require_device(x, "QuantBnConv2d")
         bias_scale = self.prepare(pre_act_scaling_factor)
         in_bits = getattr(self, "input_bit", 8)
         y = self._run_int_conv(x, pre_act_scaling_factor, self.weight_integer, self.bias_integer, bias_scale, in_bits,
-                               self.conv.stride[0], self.conv.padding[0])
+                               self.conv.stride[0], self.conv.padding[0], self.conv.groups)
         return (y, self.convbn_scaling_factor)
 
 
@@ -335,13 +367,11 @@ class QuantConv2d(_IntConvMixin, Module):
             if self.quant_mode != "asymmetric":
                 raise ValueError("unknown quant mode: {}".format(self.quant_mode))
             raise Exception('For weight, we only support symmetric quantization.')
-        if self.weight_percentile != 0:
-            raise NotImplementedError("percentile weight ranges are QAT-only (out of scope)")
-        if self.groups != 1 or self.dilation[0] != 1:
-            raise NotImplementedError("grouped/dilated convolutions are outside the ResNet hot path")
+        if self.dilation[0] != 1:
+            raise NotImplementedError("dilated convolutions are outside the path")
         _require_device(x, "QuantConv2d")
         dev = self.weight.device
-        w_int, s_w = quantize_weight_per_channel(self.weight, self.weight_bit, self.per_channel)
+        w_int, s_w = quantize_weight_per_channel(self.weight, self.weight_bit, self.per_channel, self.weight_percentile)
         self.conv_scaling_factor = s_w.to(dev)
         self.weight_integer = w_int.to(dev)
         s_a = pre_act_scaling_factor.detach().reshape(-1).float().cpu()
@@ -353,7 +383,7 @@ class QuantConv2d(_IntConvMixin, Module):
             self.bias_integer = None
             b_int = torch.zeros(self.out_channels)
         y = self._run_int_conv(x, pre_act_scaling_factor, self.weight_integer.float(), b_int.to(dev),
-                               bias_scale.to(dev), getattr(self, "input_bit", 8), self.stride[0], self.padding[0])
+                               bias_scale.to(dev), getattr(self, "input_bit", 8), self.stride[0], self.padding[0], self.groups)
         return (y, self.conv_scaling_factor)
 
 

@@ -21,6 +21,58 @@ import torch
 from . import _lib
 
 
+# --------------------------------------------------------------------------- range statistics
+_SCRATCH = {}
+
+
+def _stat_scratch(device):
+    """Per-device scratch of the statistics kernels: [2 floats out | 260 uint32 state + histogram]."""
+    key = (device.type, device.index)
+    if key not in _SCRATCH:
+        _SCRATCH[key] = (torch.zeros(2, dtype=torch.float32, device=device), torch.zeros(264, dtype=torch.int32, device=device))
+    return _SCRATCH[key]
+
+
+def device_min_max(x: torch.Tensor):
+    """(x.min(), x.max()) of a CUDA fp32 tensor as 0-dim device tensors (hawq_minmax_f32; quant_modules.py:233-236)."""
+    if not x.is_cuda:
+        raise RuntimeError("hawq_amd: activation statistics run on the MI355X only (no CPU path)")
+    x = x.contiguous().float()
+    if x.data_ptr() % 16:   # an offset view: the kernel reads 16 bytes per lane
+        x = x.clone()
+    out, scratch = _stat_scratch(x.device)
+    _lib.call("hawq_minmax_f32", x.data_ptr(), x.numel(), out.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+    r = out.clone()
+    return r[0], r[1]
+
+
+def get_percentile_min_max(input, lower_percentile, upper_percentile, output_tensor=False):
+    """The reference's percentile range (quant_utils.py:38-70), same signature: `input` a flat tensor,
+    upper bound = kthvalue(input, round(n * upper%)), lower bound = -kthvalue(-input, round(n * (1 - lower%)))
+    (0 when lower_percentile == 0).  CUDA tensors go through hawq_kthvalue_f32 (exact radix select, no sort, no host
+    round trip); host tensors (weight preparation) use torch.kthvalue."""
+    input_length = input.shape[0]
+    lower_index = round(input_length * (1 - lower_percentile * 0.01))
+    upper_index = round(input_length * upper_percentile * 0.01)
+    if input.is_cuda:
+        x = input.contiguous().float()
+        out, scratch = _stat_scratch(x.device)
+        sp = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.call("hawq_kthvalue_f32", x.data_ptr(), x.numel(), upper_index, 0, out.data_ptr(), scratch.data_ptr(), sp)
+        upper_bound = out[0].clone()
+        if lower_percentile == 0:
+            lower_bound = upper_bound * 0
+        else:
+            _lib.call("hawq_kthvalue_f32", x.data_ptr(), x.numel(), lower_index, 1, out.data_ptr(), scratch.data_ptr(), sp)
+            lower_bound = out[0].clone()
+    else:
+        upper_bound = torch.kthvalue(input, k=upper_index).values
+        lower_bound = upper_bound * 0 if lower_percentile == 0 else -torch.kthvalue(-input, k=lower_index).values
+    if not output_tensor:
+        lower_bound, upper_bound = lower_bound.item(), upper_bound.item()
+    return lower_bound, upper_bound
+
+
 # --------------------------------------------------------------------------- scale formulas
 def symmetric_linear_quantization_params(num_bits, saturation_min, saturation_max, per_channel=False):
     """S = clamp(max(|min|,|max|), 1e-8) / (2^(b-1)-1)   (quant_utils.py:128-152)."""
@@ -264,15 +316,28 @@ def fold_bn(conv_weight, bn_weight, bn_bias, running_mean, running_var, eps, con
         return scaled_weight, scaled_bias
 
 
-def quantize_weight_per_channel(w, weight_bit, per_channel=True):
-    """(weight_integer fp32-valued, scale[Cout]) as quant_modules.py:452-457, 477-480 / 97-115."""
+def quantize_weight_per_channel(w, weight_bit, per_channel=True, weight_percentile=0):
+    """(weight_integer fp32-valued, scale[Cout]) as quant_modules.py:452-480 / 97-115; with ``weight_percentile`` the
+    range is the reference's percentile range (quant_modules.py:458-474: per-channel torch.kthvalue with ceil'ed
+    indices, or get_percentile_min_max on the whole tensor).  Host tensors: parameter preparation."""
+    import math
     with torch.no_grad():
         w = w.detach().float().cpu()
         flat = w.contiguous().view(w.shape[0], -1)
         if per_channel:
-            w_min, w_max = flat.min(dim=1).values, flat.max(dim=1).values
-        else:
+            if weight_percentile == 0:
+                w_min, w_max = flat.min(dim=1).values, flat.max(dim=1).values
+            else:
+                n = flat.shape[1]
+                lower_index = math.ceil(n * (100 - weight_percentile) * 0.01)
+                upper_index = math.ceil(n * weight_percentile * 0.01)
+                w_min = torch.kthvalue(flat, k=lower_index, dim=1).values
+                w_max = torch.kthvalue(flat, k=upper_index, dim=1).values
+        elif weight_percentile == 0:
             w_min, w_max = flat.min().expand(1), flat.max().expand(1)
+        else:
+            w_min, w_max = get_percentile_min_max(w.reshape(-1), 100 - weight_percentile, weight_percentile, output_tensor=True)
+            w_min, w_max = w_min.expand(1), w_max.expand(1)
         scale = symmetric_linear_quantization_params(weight_bit, w_min, w_max, per_channel)
         if not per_channel:
             scale = scale.reshape(1)

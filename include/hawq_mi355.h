@@ -223,6 +223,23 @@ int hawq_fakequant_f32(const float *x, float *y, int64_t n, float inv_scale, flo
 /* QuantAveragePool2d on fp32 NCHW (quant_modules.py:596-602): y = trunc(avg(rint(x/S)) + 0.01) * S */
 int hawq_avgpool_f32(const float *x, float *y, int32_t NC, int32_t HW, float scale, void *stream);
 
+/* Grouped / depthwise integer conv for the module-compatible path (F.conv2d(..., groups), quant_modules.py:489-494 and
+ * 727-736; MobileNetV2's depthwise 3x3): in [N][H][W][Cin] int8, wgt [Cout][KH][KW][Cin/groups] int8, bias [Cout] or NULL
+ * -> out_acc [N][Ho][Wo][Cout] int32 (exact). */
+int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const int32_t *bias, int32_t N, int32_t H, int32_t W,
+                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t groups,
+                        int32_t *out_acc, void *stream);
+
+/* ---- range statistics of the un-frozen QuantAct (calibration / QAT range tracking) -----------------
+ * x.data.min(), x.data.max() (quant_modules.py:233-236) of a fp32 tensor -> out2[0], out2[1] (device floats).
+ * scratch: >= 8 bytes of device memory owned by the caller for the duration of the call. */
+int hawq_minmax_f32(const float *x, int64_t n, float *out2, void *scratch, void *stream);
+/* torch.kthvalue(x.view(-1), k).values (negate = 0) or -torch.kthvalue(-x.view(-1), k).values ... i.e. the k-th
+ * smallest (1-based) element of x, or of -x returned with the sign of get_percentile_min_max's use
+ * (quant_utils.py:38-70: `lower_bound = -torch.kthvalue(-input, k=lower_index).values`): out[0] = negate ? -kth(-x) : kth(x).
+ * Exact (radix select on the order-preserving integer image of the floats).  scratch: >= 1040 bytes of device memory. */
+int hawq_kthvalue_f32(const float *x, int64_t n, int64_t k, int32_t negate, float *out, void *scratch, void *stream);
+
 /* ---- hipGraph helpers: capture a sequence of the launches above once, replay per batch */
 int hawq_graph_begin(void *stream);
 int hawq_graph_end(void *stream, void **graph_exec_out);

@@ -622,3 +622,94 @@ def test_cpu_tensors_raise():
     a = qm.QuantAct(activation_bit=8)
     with pytest.raises(RuntimeError):
         a(torch.randn(1, 3, 4, 4))
+
+
+def _rec(y, s_a, s_w):
+    """integers carried by a module's fp32 output: rint(y / S_a / S_w[c])"""
+    return torch.round(y / s_a.view(1, -1, 1, 1) / s_w.view(1, -1, 1, 1))
+
+
+def test_quantconv2d_grouped_depthwise_and_percentile_match_reference_kats():
+    """QuantConv2d (quant_modules.py:605-736) - plain, grouped, depthwise (MobileNetV2's layer type), without bias,
+    4-bit weights, percentile weight ranges (per channel and per tensor) - and QuantBnConv2d with a depthwise conv:
+    module forwards against tensors recorded from the LIVE reference (tests/golden/make_kat_extra.py)."""
+    from hawq_amd import quant_modules as qm
+    kx = H.load("kat_extra.npz")
+    tags = sorted(k[len("qconv_"):-len("_cfg")] for k in kx.files if k.startswith("qconv_") and k.endswith("_cfg"))
+    assert {"c3", "c1nb", "g4", "dw", "dws2", "dw4", "pct", "pct_t"} <= set(tags)
+    for tag in tags:
+        g = lambda k: torch.from_numpy(kx[f"qconv_{tag}_{k}"])
+        cin, cout, k, stride, pad, groups, bias, wbit, pc, hw = (int(v) for v in kx[f"qconv_{tag}_cfg"])
+        pct = float(kx[f"qconv_{tag}_pct"][0])
+        conv = torch.nn.Conv2d(cin, cout, k, stride, pad, groups=groups, bias=bool(bias))
+        with torch.no_grad():
+            conv.weight.copy_(g("w"))
+            if bias:
+                conv.bias.copy_(g("b"))
+        m = qm.QuantConv2d(weight_bit=wbit, bias_bit=32 if bias else None, per_channel=bool(pc), weight_percentile=pct)
+        m.set_param(conv)
+        m = m.cuda()
+        s_a = g("s_a").cuda()
+        y, s_w = m((g("q") * g("s_a")).cuda(), s_a)
+        assert np.array_equal(s_w.cpu().numpy().reshape(-1), kx[f"qconv_{tag}_s_w"].reshape(-1)), tag
+        assert np.array_equal(m.weight_integer.cpu().numpy(), kx[f"qconv_{tag}_weight_integer"]), tag
+        if bias:
+            assert np.array_equal(m.bias_integer.cpu().numpy().reshape(-1), kx[f"qconv_{tag}_bias_integer"].reshape(-1)), tag
+        sw = s_w.cpu().reshape(-1).expand(cout) if s_w.numel() == 1 else s_w.cpu()
+        # the reference's fp32 conv runs on the un-rounded x / S_a (quant_modules.py:727-736): compare the integers it carries
+        assert torch.equal(_rec(y.cpu(), g("s_a"), sw), _rec(g("y"), g("s_a"), sw)), tag
+    for tag in ("bndw", "bndws2", "bnpct"):
+        g = lambda k: torch.from_numpy(kx[f"{tag}_{k}"])
+        c, stride, pct = int(kx[f"{tag}_cfg"][0]), int(kx[f"{tag}_cfg"][1]), float(kx[f"{tag}_cfg"][2])
+        conv = torch.nn.Conv2d(c, c, 3, stride, 1, groups=c if tag != "bnpct" else 1, bias=False)
+        bn = torch.nn.BatchNorm2d(c)
+        with torch.no_grad():
+            conv.weight.copy_(g("w")); bn.weight.copy_(g("gamma")); bn.bias.copy_(g("beta"))
+            bn.running_mean.copy_(g("mean")); bn.running_var.copy_(g("var"))
+        m = qm.QuantBnConv2d(weight_bit=8, bias_bit=32, per_channel=True, fix_BN=True, weight_percentile=pct)
+        m.set_param(conv, bn)
+        m.fix()
+        m = m.cuda().eval()
+        s_a = g("s_a").cuda()
+        y, s_w = m(((g("q") * g("s_a")).cuda(), s_a))
+        if np.array_equal(s_w.cpu().numpy(), kx[f"{tag}_s_w"]):  # else: sqrt quirk (DESIGN.md 2.2)
+            assert np.array_equal(m.weight_integer.cpu().numpy(), kx[f"{tag}_weight_integer"]), tag
+            assert np.array_equal(m.bias_integer.cpu().numpy(), kx[f"{tag}_bias_integer"]), tag
+            assert torch.equal(_rec(y.cpu(), g("s_a"), g("s_w")), _rec(g("y"), g("s_a"), g("s_w"))), tag
+
+
+def test_range_statistics_kernels_match_reference_kats(lib):
+    """hawq_minmax_f32 / hawq_kthvalue_f32 behind get_percentile_min_max and the un-frozen QuantAct (min/max and
+    percentile ranges, initialisation + momentum / running-extremum updates) against the live reference's numbers."""
+    from hawq_amd import quant_modules as qm
+    from hawq_amd.quant_utils import device_min_max, get_percentile_min_max
+    kx = H.load("kat_extra.npz")
+    for i in range(5):
+        x = torch.from_numpy(kx[f"pct{i}_x"])
+        lowp, upp = (float(v) for v in kx[f"pct{i}_cfg"])
+        lo, hi = get_percentile_min_max(x.cuda(), lowp, upp, output_tensor=True)
+        assert np.array_equal(np.array([float(lo), float(hi)], np.float32), kx[f"pct{i}_out"]), i
+        lo_h, hi_h = get_percentile_min_max(x, lowp, upp, output_tensor=True)   # host path (weight preparation)
+        assert float(lo_h) == float(lo) and float(hi_h) == float(hi)
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 5, 4096, 1000003):
+        x = torch.randn(n, generator=g)
+        lo, hi = device_min_max(x.cuda())
+        assert float(lo) == float(x.min()) and float(hi) == float(x.max())
+        for k in {1, (n + 1) // 2, n}:
+            out = torch.zeros(1, device='cuda')
+            scratch = torch.zeros(264, dtype=torch.int32, device='cuda')
+            xd = x.cuda()
+            lib.call("hawq_kthvalue_f32", xd.data_ptr(), n, k, 0, out.data_ptr(), scratch.data_ptr(), stream())
+            assert float(out) == float(torch.kthvalue(x, k).values), (n, k)
+            lib.call("hawq_kthvalue_f32", xd.data_ptr(), n, k, 1, out.data_ptr(), scratch.data_ptr(), stream())
+            assert float(out) == float(-torch.kthvalue(-x, k).values), (n, k)
+    for tag in ("mm", "mmx", "ps", "pa"):
+        bits, pct, mom = kx[f"act_{tag}_cfg"]
+        a = qm.QuantAct(activation_bit=int(bits), act_range_momentum=float(mom) if mom != -1 else -1,
+                        quant_mode="asymmetric" if tag == "pa" else "symmetric", act_percentile=float(pct)).cuda()
+        for it in range(3):
+            y, s = a(torch.from_numpy(kx[f"act_{tag}_x"][it]).cuda())
+            got = np.array([float(a.x_min), float(a.x_max), float(s)], np.float32)
+            assert np.array_equal(got, kx[f"act_{tag}_rng"][it]), (tag, it, got, kx[f"act_{tag}_rng"][it])
+            assert np.array_equal(y.cpu().numpy(), kx[f"act_{tag}_y"][it]), (tag, it)
