@@ -11,12 +11,18 @@ from .skeleton import build_float_resnet, init_synthetic
 
 
 def build_quantized_resnet(arch: str, scheme: str, seed: int | None = 0, float_model=None):
-    """Float skeleton (synthetic weights unless ``float_model`` is given) -> Q_ResNet with the
-    ``bit_config_<arch>_<scheme>`` schedule applied; eval mode, un-frozen."""
-    fl = float_model if float_model is not None else build_float_resnet(arch)
+    """Float skeleton (synthetic weights unless ``float_model`` is given) -> Q_ResNet (or, ``mobilenetv2_w1``,
+    Q_MobileNetV2) with the ``bit_config_<arch>_<scheme>`` schedule applied; eval mode, un-frozen."""
+    if arch == "mobilenetv2_w1":
+        from .q_mobilenetv2 import q_mobilenetv2_w1
+        from .skeleton import build_float_mobilenetv2
+        build, quantize = build_float_mobilenetv2, q_mobilenetv2_w1
+    else:
+        build, quantize = (lambda: build_float_resnet(arch)), quantize_arch_dict[arch]
+    fl = float_model if float_model is not None else build()
     if float_model is None and seed is not None:
         init_synthetic(fl, seed)
-    q = quantize_arch_dict[arch](fl)
+    q = quantize(fl)
     apply_bit_config(q, get_bit_config(arch, scheme))
     q.eval()
     return q
@@ -153,3 +159,6 @@ def validate(model, loader, uint8: bool = False, mean=(0.485, 0.456, 0.406), std
             top5 += float(correct[:5].reshape(-1).float().sum())
             n += int(target.size(0))
     return 100.0 * top1 / max(n, 1), 100.0 * top5 / max(n, 1), n
+
+
+build_quantized_model = build_quantized_resnet   # the name says ResNet for history; MobileNetV2 goes through it too

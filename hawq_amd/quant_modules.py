@@ -273,6 +273,12 @@ class QuantBnConv2d(_IntConvMixin, Module):
                self.weight_percentile, float(s_a[0]))
         if getattr(self, "_prep_key", None) == key:
             return self._prep_bias_scale
+        if getattr(self, "use_integer_buffers", False):
+            # integer weights / biases / scales as loaded (quantized_checkpoint.pth.tar, quant_train.py:665-670): nothing is
+            # re-derived from the float parameters
+            bias_scale = self.convbn_scaling_factor.detach().float().cpu().view(1, -1) * s_a.view(1, -1)
+            self._prep_key, self._prep_bias_scale = key, bias_scale.to(c.weight.device)
+            return self._prep_bias_scale
         if self.quant_mode != 'symmetric':
             raise Exception('For weight, we only support symmetric quantization.')
         dev = c.weight.device
@@ -371,9 +377,12 @@ class QuantConv2d(_IntConvMixin, Module):
             raise NotImplementedError("dilated convolutions are outside the path")
         _require_device(x, "QuantConv2d")
         dev = self.weight.device
-        w_int, s_w = quantize_weight_per_channel(self.weight, self.weight_bit, self.per_channel, self.weight_percentile)
-        self.conv_scaling_factor = s_w.to(dev)
-        self.weight_integer = w_int.to(dev)
+        if getattr(self, "use_integer_buffers", False):   # integer weights / scales as loaded, see QuantBnConv2d.prepare
+            w_int, s_w = self.weight_integer.detach().float().cpu(), self.conv_scaling_factor.detach().float().cpu()
+        else:
+            w_int, s_w = quantize_weight_per_channel(self.weight, self.weight_bit, self.per_channel, self.weight_percentile)
+            self.conv_scaling_factor = s_w.to(dev)
+            self.weight_integer = w_int.to(dev)
         s_a = pre_act_scaling_factor.detach().reshape(-1).float().cpu()
         if self.quantize_bias and (self.bias is not None):
             b_int, bias_scale = quantize_bias(self.bias, s_w, s_a, self.bias_bit)

@@ -68,6 +68,43 @@ def build_float_resnet(arch: str, num_classes: int = 1000) -> nn.Module:
     return net
 
 
+def build_float_mobilenetv2(num_classes: int = 1000) -> nn.Module:
+    """pytorchcv ``mobilenetv2_w1`` attribute tree as utils/models/q_mobilenetv2.py:120-172 dereferences it:
+    ``features.init_block.{conv,bn}`` (3x3/2, 3->32), ``features.stageN.unitM.{conv1,conv2,conv3}.{conv,bn}`` (1x1 expand x6 -
+    x1 in the very first unit -, 3x3 depthwise, 1x1 linear projection), ``features.final_block.{conv,bn}`` (1x1 320->1280),
+    ``features.final_pool`` (AvgPool2d(7)), ``output`` (1x1 conv, no bias)."""
+    layers, downsample, widths = [1, 2, 3, 4, 3, 3, 1], [0, 1, 1, 1, 0, 1, 0], [16, 24, 32, 64, 96, 160, 320]
+    channels = [[]]
+    for c, n, d in zip(widths, layers, downsample):   # q_get_mobilenetv2's grouping (q_mobilenetv2.py:224-233)
+        if d:
+            channels.append([c] * n)
+        else:
+            channels[-1] += [c] * n
+    net = nn.Module()
+    net.arch = "mobilenetv2_w1"
+    net.features = nn.Module()
+    net.features.init_block = _conv_bn(3, 32, 3, 2, 1)
+    cin = 32
+    for si, per_stage in enumerate(channels):
+        stage = nn.Module()
+        for ui, cout in enumerate(per_stage):
+            stride = 2 if (ui == 0 and si != 0) else 1
+            mid = cin * 6 if (si != 0 or ui != 0) else cin
+            u = nn.Module()
+            u.conv1 = _conv_bn(cin, mid, 1, 1, 0)
+            u.conv2 = _conv_bn(mid, mid, 3, stride, 1)
+            u.conv2.conv = nn.Conv2d(mid, mid, 3, stride, 1, groups=mid, bias=False)
+            u.conv3 = _conv_bn(mid, cout, 1, 1, 0)
+            setattr(stage, f"unit{ui + 1}", u)
+            cin = cout
+        setattr(net.features, f"stage{si + 1}", stage)
+    net.features.final_block = _conv_bn(cin, 1280, 1, 1, 0)
+    net.features.final_pool = nn.AvgPool2d(kernel_size=7, stride=1)
+    net.output = nn.Conv2d(1280, num_classes, 1, bias=False)
+    net.channels = channels
+    return net
+
+
 def init_synthetic(net: nn.Module, seed: int = 0) -> nn.Module:
     """Deterministic synthetic weights (no zoo checkpoints are reachable here).
 

@@ -103,5 +103,57 @@ def main():
     print("wrote kat_extra.npz with", len(out), "arrays")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--mobilenet" not in sys.argv:
     main()
+
+
+def mobilenet_fixture(scheme, batch=2):
+    """Whole-network fixture of the LIVE reference's Q_MobileNetV2 (q_mobilenetv2.py): frozen ranges, integer buffers
+    (scales + biases in full; weight_integer as SHA-256 per layer plus the entries where torch-CPU's non-IEEE sqrt moved
+    a weight relative to hawq_amd's IEEE preparation), logits."""
+    import hashlib
+    from hawq_amd.api import build_quantized_model
+    from hawq_amd.skeleton import synthetic_images
+    qr, qm, qu = ref_live.load_reference()
+    q = ref_live.build_reference_model("mobilenetv2_w1", scheme, seed=0)
+    x = synthetic_images(batch, seed=0)
+    ref_live.calibrate_and_freeze(q, x)
+    with torch.no_grad():
+        y = q(x)
+    ours = build_quantized_model("mobilenetv2_w1", scheme, seed=0)
+    out = dict(logits=y.numpy(), top1=y.argmax(1).numpy(), input_sha=np.array(hashlib.sha256(x.numpy().tobytes()).hexdigest()))
+    acts = [(n, m) for n, m in q.named_modules() if type(m).__name__ == "QuantAct"]
+    out["act_names"] = np.array([n for n, _ in acts])
+    out["act_x_min"] = np.array([float(m.x_min) for _, m in acts], np.float32)
+    out["act_x_max"] = np.array([float(m.x_max) for _, m in acts], np.float32)
+    out["act_scale"] = np.array([float(m.act_scaling_factor.reshape(-1)[0]) for _, m in acts], np.float32)
+    convs = [(n, m) for n, m in q.named_modules() if type(m).__name__ in ("QuantBnConv2d", "QuantConv2d")]
+    mine = dict(ours.named_modules())
+    names, scales, biases, shas, patches = [], [], [], [], []
+    s_prev = {}
+    for li, (n, m) in enumerate(convs):
+        names.append(n)
+        sc = (m.convbn_scaling_factor if type(m).__name__ == "QuantBnConv2d" else m.conv_scaling_factor).detach().reshape(-1)
+        scales.append(sc.numpy().astype(np.float32))
+        b = m.bias_integer
+        biases.append(np.zeros(sc.numel(), np.float64) if b is None else b.detach().reshape(-1).numpy().astype(np.float64))
+        w_ref = m.weight_integer.detach().float().numpy()
+        shas.append(hashlib.sha256(np.ascontiguousarray(w_ref.astype(np.int8)).tobytes()).hexdigest())
+        mm = mine[n]
+        if type(m).__name__ == "QuantBnConv2d":   # hawq_amd's own (IEEE) preparation, on the host
+            mm.prepare(torch.ones(1))
+        else:
+            from hawq_amd.quant_utils import quantize_weight_per_channel
+            mm.weight_integer = quantize_weight_per_channel(mm.weight, mm.weight_bit, mm.per_channel, mm.weight_percentile)[0]
+        w_own = mm.weight_integer.detach().float().numpy()
+        for idx in np.nonzero(w_own.reshape(-1) != w_ref.reshape(-1))[0]:
+            patches.append((li, int(idx), int(w_ref.reshape(-1)[idx])))
+    out.update(conv_names=np.array(names), conv_scale=np.concatenate(scales), conv_bias=np.concatenate(biases),
+               conv_wsha=np.array(shas), conv_wpatch=np.array(patches, np.int64).reshape(-1, 3))
+    np.savez_compressed(os.path.join(HERE, f"net_mobilenetv2_w1_{scheme}_b{batch}.npz"), **out)
+    print("mobilenetv2_w1", scheme, "top1", out["top1"], "weight patches", len(patches), flush=True)
+
+
+if __name__ == "__main__" and "--mobilenet" in sys.argv:
+    for scheme in ("uniform8", "uniform4", "bops_0.5"):
+        mobilenet_fixture(scheme)

@@ -228,3 +228,21 @@ def test_roofline_model_reproduces_survey_numbers():
         assert abs(roofline.algorithmic_bytes(a, s, 128) / 1e9 - gb) < 5e-4
     assert abs(roofline.macs("resnet50", "uniform8", 128) / 1e9 - 493.8) < 0.1
     assert abs(roofline.macs("resnet18", "uniform8", 128) / 1e9 - 232.2) < 0.1
+
+
+def test_mobilenetv2_graph_and_schedules_line_up():
+    """Q_MobileNetV2 (q_mobilenetv2.py) builds for every shipped schedule: each schedule entry names a module (incl. the two
+    stray `conv1.conv` / `conv1.bn` entries of three reference schedules), units alternate 1x1 / depthwise 3x3 / 1x1."""
+    from hawq_amd.api import build_quantized_model
+    from hawq_amd.bit_schedules import get_bit_config
+    from hawq_amd.quant_modules import QuantAct, QuantBnConv2d, QuantConv2d
+    for scheme in ("uniform8", "uniform4", "bops_0.5", "modelsize_0.5"):
+        m = build_quantized_model("mobilenetv2_w1", scheme, seed=None)
+        cfg = get_bit_config("mobilenetv2_w1", scheme)
+        mods = dict(m.named_modules())
+        assert all(k in mods for k in cfg)
+        convs = [v for v in mods.values() if isinstance(v, QuantBnConv2d)]
+        assert len(convs) == 1 + 17 * 3 + 1 and isinstance(m.output, QuantConv2d)
+        assert sum(c.conv.groups > 1 for c in convs) == 17 and all(c.conv.groups == c.conv.in_channels for c in convs if c.conv.groups > 1)
+        assert sum(isinstance(v, QuantAct) for v in mods.values()) == 2 + 17 * 4 + 3
+        assert mods["features.stage4.unit5.conv2"].weight_bit == cfg["features.stage4.unit5.conv2"]
