@@ -166,7 +166,7 @@ def test_packing_roundtrip_and_layout():
 def test_bit_schedules_and_module_tree():
     from hawq_amd.api import build_quantized_resnet
     from hawq_amd.bit_schedules import bit_config_dict, module_names
-    assert len(bit_config_dict) == 26
+    assert len(bit_config_dict) == 30 and sum(k.startswith("bit_config_resnet") for k in bit_config_dict) == 26
     for arch, scheme in H.NET_CONFIGS:
         q = build_quantized_resnet(arch, scheme, seed=None)
         names = dict(q.named_modules())
