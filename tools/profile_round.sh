@@ -1,18 +1,26 @@
 #!/bin/bash
-# Evidence for profiles/: run ON the GPU box (gpurun -- 'bash tools/profile_round.sh r01_c').  Writes gpurun_out/<tag>_*.
+# Evidence for profiles/: run ON the GPU box
+#   gpurun -- 'GRAFT_HEAD=<git head> bash tools/profile_round.sh r02_c'
+# Writes gpurun_out/<tag>_*: default bench line, single-chain per-launch table, rocprofv3 kernel trace of a run that
+# replays the recorded tile / fused-variant / sub-batch choice (so the trace holds forwards only), HBM traffic (separate
+# FETCH_SIZE / WRITE_SIZE PMC passes, counter totals at --steps 12 minus --steps 2), MFMA / VALU utilisation counters
+# per kernel, and <tag>_traffic.json (copy to profiles/traffic.json).
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-HAWQ_CHAINS=1 python bench.py --no-cpu-baseline --per-op $O/${tag}_perop_single_chain.md > $O/${tag}_bench_single_chain.json 2>/dev/null
+python bench.py ${BENCH_ARGS} > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+HAWQ_CHAINS=1 python bench.py --no-cpu-baseline --no-extra --per-op $O/${tag}_perop_single_chain.md > $O/${tag}_bench_single_chain.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-# the trace replays the tile / sub-batch choice of the run above, so that it holds no tuning launches
-export HAWQ_TILES=$(python -c "import json,sys; print(json.load(open('$O/${tag}_bench.json'))['config']['autotuned_tiles'])")
-export HAWQ_CHAINS=$(python -c "import json,sys; print(json.load(open('$O/${tag}_bench.json'))['config']['concurrent_sub_batches'])")
+cfg() { python -c "import json; print(json.loads(open('$O/${tag}_bench.json').readline())['config']['$1'])"; }
+export HAWQ_TILES=$(cfg autotuned_tiles)
+export HAWQ_CHAINS=$(cfg concurrent_sub_batches)
+export HAWQ_ER_TILES=$(cfg fused_variants)
+export HAWQ_ER_SPLIT_TILES=$(cfg fused_split_tiles)
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.py --no-cpu-baseline --no-extra --steps 20 --warmup 5 > $O/${tag}_bench_under_rocprof.json 2>/dev/null
 python $R/tools/rocprof_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${tag}_kernel_trace.md
+rm -f $O/${tag}_pmc_totals.txt
 for ctr in FETCH_SIZE WRITE_SIZE; do
   for steps in 2 12; do
     rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm -o r -- python $R/bench.py --no-cpu-baseline --no-extra --steps $steps --warmup 1 > /dev/null 2>&1
@@ -20,4 +28,26 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     if [ $steps = 12 ]; then python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) 20 > $O/${tag}_pmc_${ctr}.md; fi
   done
 done
+# matrix-pipe / VALU utilisation per kernel (north_star: "rocprof HBM GB/s and MFMA utilisation")
+rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $R/bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 1 > /dev/null 2>&1
+python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) 8 > $O/${tag}_pmc_MFMA.md
+python $R/tools/pmc_total.py $(find /tmp/pm -name "*.db" | head -1) > $O/${tag}_pmc_MFMA_totals.txt
+python - <<PY
+import json, re
+tot = {}
+for line in open("$O/${tag}_pmc_totals.txt"):
+    m = re.match(r"(\w+) steps=(\d+) \1 ([\d.e+]+) (\d+)", line)
+    if m:
+        tot[(m[1], int(m[2]))] = float(m[3])
+fetch_kb = (tot[("FETCH_SIZE", 12)] - tot[("FETCH_SIZE", 2)]) / 10
+write_kb = (tot[("WRITE_SIZE", 12)] - tot[("WRITE_SIZE", 2)]) / 10
+b = json.loads(open("$O/${tag}_bench.json").readline())
+out = {b["config"]["workload"]: {
+    "bytes_per_launch": round((2 * fetch_kb + write_kb) * 1000.0), "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+    "git_head": "${GRAFT_HEAD:-unknown}", "tag": "$tag",
+    "config": f"{b['config']['concurrent_sub_batches']} concurrent sub-batches, tiles {b['config']['autotuned_tiles']}, fused variants {b['config']['fused_variants']} replayed",
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only), counter summed over ALL dispatches of bench.py --no-cpu-baseline --no-extra --warmup 1 at --steps 12 minus the same at --steps 2, divided by 10 forwards (tools/profile_round.sh, tools/pmc_total.py); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16 B/lane streams); KB = 1000 B"}}
+json.dump(out, open("$O/${tag}_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
 cat $O/${tag}_pmc_totals.txt
