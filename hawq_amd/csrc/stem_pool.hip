@@ -154,7 +154,7 @@ constexpr int SF_PATCH = 39 * SF_PW * 4;        // bytes per image patch
 // table lut[c][u] = QuantAct(normalise_c(u / 255)) built on the host with the reference's own float operations
 // (hawq_amd.engine.input_lut): the input quantiser becomes a table look-up - exact, and the input read shrinks 4x.
 template <bool U8>
-__global__ __launch_bounds__(256, 2) void stem_fused_kernel(
+__global__ __launch_bounds__(256, 4) void stem_fused_kernel(
     const float *__restrict__ x, const uint8_t *__restrict__ xu8, const int8_t *__restrict__ lut,
     int N, int Cin, int H, int W, float inv_scale, int in_lo, int in_hi,
     const int8_t *__restrict__ wgt, const int32_t *__restrict__ bias, const int32_t *__restrict__ m,
@@ -306,19 +306,19 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
     const char *pbase = patch + img * SF_PATCH + ((4 * pr) * SF_PW + 4 * pc + 4 * h) * 4;
     const size_t opix = ((size_t)n * Hp + py) * Wp + px;
 
-    // both 32-channel halves share every B fragment read from the LDS patch (the LDS read port, not the
-    // MFMA pipe, is the scarce resource here)
-    v4i wf[2][7];
+    // The two 32-channel halves are walked one after the other: weights of ONE half (7 fragments, 28 VGPRs), one
+    // accumulator tile and one running maximum live at a time - 80 instead of 138 VGPRs, 6 instead of 3 workgroups per
+    // CU, whose fill (HBM), MFMA and max / requant (VALU) phases then overlap.  The price is reading every B fragment of
+    // the LDS patch twice: 2 x 126 ds_read_b64 per wave, ~500 LDS cycles beside 4000 cycles of MFMA.
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+    v4i wf[7];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int kh = 0; kh < 7; ++kh)
+        wf[kh] = *reinterpret_cast<const v4i *>(wgt + ((c * 32 + cperm(l31)) * 7 + kh) * 32 + h * 16);
+    int best[16];
 #pragma unroll
-        for (int kh = 0; kh < 7; ++kh)
-            wf[c][kh] = *reinterpret_cast<const v4i *>(wgt + ((c * 32 + cperm(l31)) * 7 + kh) * 32 + h * 16);
-    int best[2][16];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) best[c][r] = (int)0x80000000;
+    for (int r = 0; r < 16; ++r) best[r] = (int)0x80000000;
 #pragma unroll 1
     for (int dy = 0; dy < ((dbg & 32) ? 1 : 3); ++dy) {  // not unrolled: keeps the 9 window tiles from living at once
         const int cy = 2 * py + dy - 1;
@@ -326,26 +326,21 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
         for (int dx = 0; dx < 3; ++dx) {
             const int cx = 2 * px + dx - 1;
             const bool cvalid = (unsigned)cy < (unsigned)Hc && (unsigned)cx < (unsigned)Wc;
-            v16i acc0, acc1;
+            v16i acc0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
+            for (int r = 0; r < 16; ++r) acc0[r] = 0;
 #pragma unroll
             for (int kh = 0; kh < 7; ++kh) {
                 const char *s0 = pbase + ((2 * dy + kh) * SF_PW + 2 * dx) * 4;  // 8-byte aligned
                 const v2i a0 = *reinterpret_cast<const v2i *>(s0), a1 = *reinterpret_cast<const v2i *>(s0 + 8);
                 v4i af = {a0.x, a0.y, a1.x, a1.y};
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][kh], af, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[1][kh], af, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kh], af, acc0, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                best[0][r] = max(best[0][r], cvalid ? acc0[r] : (int)0x80000000);
-                best[1][r] = max(best[1][r], cvalid ? acc1[r] : (int)0x80000000);
-            }
+            for (int r = 0; r < 16; ++r) best[r] = max(best[r], cvalid ? acc0[r] : (int)0x80000000);
         }
     }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    {
         if (!pvalid || (dbg & 64)) continue;
         const int ch = c * 32 + h * 16;
         int r16[16], qa[16];
@@ -358,14 +353,14 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
                 const DyNt dq = dynt_prepare(mq, eq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int v = max(clampi(dyadic_nt(best[c][4 * g + j] + bb[j], dynt_prepare(mm[j], ee[j])), a_lo, a_hi), 0);
+                    const int v = max(clampi(dyadic_nt(best[4 * g + j] + bb[j], dynt_prepare(mm[j], ee[j])), a_lo, a_hi), 0);
                     r16[4 * g + j] = v;
                     qa[4 * g + j] = clampi(dyadic_nt(v, dq), q_lo, q_hi);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int v = max(clampi(dyadic_rne(best[c][4 * g + j] + bb[j], mm[j], ee[j]), a_lo, a_hi), 0);
+                    const int v = max(clampi(dyadic_rne(best[4 * g + j] + bb[j], mm[j], ee[j]), a_lo, a_hi), 0);
                     r16[4 * g + j] = v;
                     qa[4 * g + j] = clampi(dyadic_rne(v, mq, eq), q_lo, q_hi);
                 }
@@ -390,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void stem_fused_kernel(
             }
         }
     }
+    }  // c
 }
 
 // ------------------------------------------------------------------ 3x3/2 max-pool (+ QuantAct)
