@@ -52,25 +52,32 @@ struct ConvP {
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
 
-template <int BM_, int BN_, int WM_, int WN_, int NS_, int KSUB_ = 1, int MINB_ = 2>
+template <int BM_, int BN_, int WM_, int WN_, int NS_, int KSUB_ = 1, int MINB_ = 2, int KG_ = 1>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-    static constexpr int MINB = MINB_;       // workgroups per CU the register allocation must allow
+    static constexpr int MINB = MINB_;       // waves per SIMD the register allocation must allow (launch_bounds)
     static constexpr int NS = NS_;           // LDS ring stages of the asynchronous (global_load_lds) pipeline
     static constexpr int KSUB = KSUB_;       // 64-channel sub-chunks per ring stage (one barrier per stage)
-    static constexpr int NW = WM_ * WN_;     // waves per workgroup (4 or 8)
+    // KG > 1: intra-workgroup split-K.  KG groups of WM x WN waves each own the sub-chunks sub % KG == group of every ring
+    // stage - they issue their LDS-DMA and run their MFMAs - and the partial accumulators are summed through LDS before
+    // the epilogue.  For the long-K, few-pixel layers (reduce convs of stages 3-4, FC): the K loop of a tile is bound by
+    // the per-wave LDS-DMA rate, so KG x the issuing waves per tile shortens it almost KG-fold.
+    static constexpr int KG = KG_;
+    static constexpr int NWG = WM_ * WN_;    // waves per K group
+    static constexpr int NW = NWG * KG;      // waves per workgroup
     static constexpr int NT = NW * 64;       // threads per workgroup
-    static constexpr int RPP = NT / 4;       // operand rows staged per pass (4 lanes x 16 B per 64-B row)
+    static constexpr int NTG = NWG * 64;     // threads per K group
+    static constexpr int RPP = NTG / 4;      // operand rows staged per pass of a K group (4 lanes x 16 B per 64-B row)
     static constexpr int PT = BM / WM / 32;  // pixel MFMA tiles per wave
     static constexpr int CT = BN / WN / 32;  // channel MFMA tiles per wave
-    static constexpr int AL = BM / RPP;      // 16-B A loads per thread per chunk
+    static constexpr int AL = BM / RPP;      // 16-B A loads per thread per sub-chunk
     static constexpr int WL = BN / RPP;
     static constexpr int STAGE_BYTES = KSUB * (BM + BN) * 64;
     static constexpr int LDS_BYTES = NS * STAGE_BYTES;  // the register-staged path uses the first two stages
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must fill whole staging passes");
+    static_assert(KSUB % KG == 0 && (KG == 1 || BM * BN * 4 <= LDS_BYTES), "split-K: sub-chunks per group, partial sums staged on the ring");
 };
-
 
 // 8 bytes of hawq4 (16 channels) -> 16 int8.  Unsigned: zero-extended.  Signed weights come
 // out as value*16 (nibble moved to the top of its byte); the accumulator is shifted back by 4
@@ -267,11 +274,12 @@ __device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&
                                               const ConvP &p, int m0, int c0, char *smem) {
     constexpr int CSH = NIB ? 7 : 6;  // log2(channels per 64-byte chunk)
     constexpr int NS = C::NS, L = C::AL + C::WL, STAGE = C::STAGE_BYTES;
-    static_assert((NS - 2) * L * C::KSUB <= 60, "vmcnt range");
+    static_assert((NS - 2) * L * C::KSUB / C::KG <= 60, "vmcnt range");
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = (t >> 6) % C::NWG, kg = (t >> 6) / C::NWG;   // wave inside its K group, K group
     const int wave_m = wave % C::WM, wave_c = wave / C::WM;
-    const int lrow = t >> 2, lslot = t & 3;
+    const int tg = t % C::NTG;                                                    // thread inside its K group
+    const int lrow = tg >> 2, lslot = tg & 3;
     const char *zero = reinterpret_cast<const char *>(g_zero16);
 
     // im2col bookkeeping of this thread's rows (first branch) and of the second branch's 1x1/stride-s2 rows
@@ -307,6 +315,20 @@ __device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&
     auto issue_sub = [&](int sub) {
         char *sa = smem + istage * STAGE + sub * SUBB + wave * 1024;  // + i * RPP * 64: RPP rows x 64 B per pass
         char *sw = sa + C::BM * 64;
+        const bool mine = C::KG == 1 || (sub % C::KG) == kg;           // split-K: the sub-chunk's own group loads it
+        if (!mine) {
+            if (!DUAL || jissue < nk1) {
+                if (++cc == cch1) {
+                    cc = 0;
+                    if (++kw == p.KW) {
+                        kw = 0;
+                        ++kh;
+                    }
+                }
+            }
+            ++jissue;
+            return;
+        }
         if (!DUAL || jissue < nk1) {
             const int tap_off = kh * p.W + kw;
 #pragma unroll
@@ -387,15 +409,18 @@ __device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&
 #pragma unroll
             for (int q = 0; q < C::PT; ++q) af[buf][q] = *reinterpret_cast<const v4i *>(ldsA + lds_off(arow[q], slot));
         };
-        fetch(0, 0);
+        // the K-steps this wave owns: all of the stage, or (split-K) those of the sub-chunks sub % KG == kg
+        constexpr int NOWN = SPS * KSUB / C::KG;
+        auto step_of = [&](int o) { return C::KG == 1 ? o : ((o / SPS) * C::KG + kg) * SPS + (o % SPS); };
+        fetch(step_of(0), 0);
 #pragma unroll
-        for (int s = 0; s < SPS * KSUB; ++s) {
-            if (s + 1 < SPS * KSUB) fetch(s + 1, (s + 1) & 1);
+        for (int o = 0; o < NOWN; ++o) {
+            if (o + 1 < NOWN) fetch(step_of(o + 1), (o + 1) & 1);
 #pragma unroll
             for (int c = 0; c < C::CT; ++c)
 #pragma unroll
                 for (int q = 0; q < C::PT; ++q)
-                    a[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[s & 1][c], af[s & 1][q], a[c][q], 0, 0, 0);
+                    a[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[o & 1][c], af[o & 1][q], a[c][q], 0, 0, 0);
         }
     };
 
@@ -404,7 +429,7 @@ __device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&
     for (int j = 0; j < NS - 1; ++j)
         if (j < nst) issue();
     int cstage = 0;
-    constexpr int LS = L * KSUB;  // loads per thread per stage
+    constexpr int LS = L * KSUB / C::KG;  // loads per thread per stage
     auto step = [&](auto &a, int k) {
         // stage k must have landed: at most min(NS-2, stages issued after k) stages may stay in flight
         const int after = min(NS - 2, nst - 1 - k);
@@ -578,8 +603,9 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
     using S = Stage<C>;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int i = 0; i < C::BM * S::RCPR / C::NT; ++i) {
+    for (int i = 0; i < (C::BM * S::RCPR + C::NT - 1) / C::NT; ++i) {
         const int base = (i * C::NW + wave) * 64;
+        if (base >= C::BM * S::RCPR) break;   // (16-wave workgroups on a 64-pixel tile: half of the waves have no piece)
         const int idx = base + lane;
         const int row = idx / S::RCPR, j = idx % S::RCPR;
         const int grow = (m0 + row < p.M) ? m0 + row : m0;
@@ -718,10 +744,10 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     if constexpr (RES) {
         if (p.res_out) {
 #pragma unroll
-            for (int i = 0; i < C::BM * S::RCPR / C::NT; ++i) {
+            for (int i = 0; i < (C::BM * S::RCPR + C::NT - 1) / C::NT; ++i) {
                 const int idx = t + C::NT * i;
                 const int row = idx / S::RCPR, j = idx % S::RCPR;
-                if (m0 + row < p.M) {
+                if (idx < C::BM * S::RCPR && m0 + row < p.M) {
                     char *dst = (char *)p.res_out + ((size_t)(m0 + row) * p.Cout + c0) * 2 + ((j ^ S::rsw(row)) << 4);
                     *reinterpret_cast<v4i *>(dst) = *reinterpret_cast<const v4i *>(res_tile + idx * 16);
                 }
@@ -844,10 +870,59 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     }
     if (p.dbg & 4) return;
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
-    if constexpr (FAST)
-        epilogue_fast<C, EPI, DUAL, TIE ? 2 : 0>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds);
-    else
+    const int kgrp = (threadIdx.x >> 6) / C::NWG;
+    if constexpr (C::KG > 1) {
+        // split-K: groups 1 .. KG-1 hand their partial accumulators to group 0 through the (now free) ring, one group per
+        // round; [wave][tile][register][lane] dwords: conflict-free, every lane finds its own registers
+        int *dump = reinterpret_cast<int *>(smem);
+        const int slot0 = (((threadIdx.x >> 6) % C::NWG) * (C::CT * C::PT)) * 16 * 64 + (threadIdx.x & 63);
+        for (int g = 1; g < C::KG; ++g) {
+            if (kgrp == g) {
+#pragma unroll
+                for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+                    for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dump[slot0 + ((c * C::PT + q) * 16 + r) * 64] = acc[c][q][r];
+            }
+            __syncthreads();
+            if (kgrp == 0) {
+#pragma unroll
+                for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+                    for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[c][q][r] += dump[slot0 + ((c * C::PT + q) * 16 + r) * 64];
+            }
+            __syncthreads();
+            if constexpr (DUAL) {
+                if (kgrp == g) {
+#pragma unroll
+                    for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+                        for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) dump[slot0 + ((c * C::PT + q) * 16 + r) * 64] = acc2[DUAL ? c : 0][DUAL ? q : 0][r];
+                }
+                __syncthreads();
+                if (kgrp == 0) {
+#pragma unroll
+                    for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+                        for (int q = 0; q < C::PT; ++q)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc2[DUAL ? c : 0][DUAL ? q : 0][r] += dump[slot0 + ((c * C::PT + q) * 16 + r) * 64];
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if constexpr (FAST) {
+        epilogue_fast<C, EPI, DUAL, TIE ? 2 : 0>(p, acc, acc2, m0, c0, smem, res_tile, ctab_lds, kgrp == 0);
+    } else {
+        if (C::KG > 1 && kgrp != 0) return;   // the direct epilogue has no barriers: the other groups are done
         epilogue_generic<C, EPI, DUAL>(p, acc, acc2, m0, c0);
+    }
     if (prof && blockIdx.x == 8 && threadIdx.x == 0) {
         p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
         p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = 0;
@@ -1227,12 +1302,17 @@ using T10 = Cfg<64, 64, 2, 2, 3, 1, 6>;
 using T11 = Cfg<64, 64, 2, 2, 2, 1, 6>;
 using T12 = Cfg<128, 64, 2, 2, 2, 1, 3>;
 using T13 = Cfg<128, 128, 2, 4, 2, 1, 2>;
-constexpr int NUM_TILES = 14;
+// intra-workgroup split-K (KG groups of waves on alternating 64-channel sub-chunks) for the long-K, few-pixel layers
+using T14 = Cfg<64, 64, 2, 2, 3, 2, 4, 2>;     // 8 waves: 2 groups x (2 x 2 waves of 32 x 32), 48 KiB
+// (measured, not kept: 16 waves in 4 K groups, and 5-6-stage rings for the same layers - 96-120 KiB of LDS leave one workgroup
+// per CU, and these launches live on the overlap BETWEEN workgroups: 15-60 % slower.  Split-K itself ties with the best
+// plain tile; it stays as an autotuner choice.)
+constexpr int NUM_TILES = 15;
 
 // single-branch kernels: epilogue {RAW, REQUANT, RESIDUAL, DEQUANT} x bit variant {run-time, 8/8, 4/4};
 // dual-branch (RESIDUAL + identity conv): {run-time, 88/88, 44/44, 88/44, 44/88}
 struct TileInfo {
-    int BM, BN, lds, ksub, twin, nt, ns;  // twin: tile id to fall back to when KSUB == 2 does not divide the chunk count
+    int BM, BN, lds, ksub, twin, nt, ns, kg;  // twin: tile id to fall back to when KSUB does not divide the chunk count / the layer is not on the asynchronous pipeline
     KernelFn single[4][3];
     KernelFn dual[5];
     KernelFn tie_single[2][2];  // exact-tie instantiations: {REQUANT, RESIDUAL} x {8/8, 4/4}
@@ -1242,7 +1322,7 @@ struct TileInfo {
     { conv_kernel<T, E, false, 0, 0>, conv_kernel<T, E, false, 0x88, 0>, conv_kernel<T, E, false, 0x44, 0> }
 #define TILE_ENTRY(T, TWIN)                                                                                          \
     {                                                                                                          \
-        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN, T::NT, T::NS,                                                          \
+        T::BM, T::BN, T::LDS_BYTES, T::KSUB, TWIN, T::NT, T::NS, T::KG,                                                   \
             {SINGLE_ROW(T, HAWQ_EPI_RAW), SINGLE_ROW(T, HAWQ_EPI_REQUANT), SINGLE_ROW(T, HAWQ_EPI_RESIDUAL),   \
              SINGLE_ROW(T, HAWQ_EPI_DEQUANT)},                                                                 \
         {                                                                                                      \
@@ -1258,7 +1338,8 @@ struct TileInfo {
 const TileInfo kTiles[NUM_TILES] = {TILE_ENTRY(T0, 0), TILE_ENTRY(T1, 1), TILE_ENTRY(T2, 2), TILE_ENTRY(T3, 3),
                                     TILE_ENTRY(T4, 0), TILE_ENTRY(T5, 2), TILE_ENTRY(T6, 3),
                                     TILE_ENTRY(T7, 7), TILE_ENTRY(T8, 7), TILE_ENTRY(T9, 9),
-                                    TILE_ENTRY(T10, 10), TILE_ENTRY(T11, 11), TILE_ENTRY(T12, 12), TILE_ENTRY(T13, 13)};
+                                    TILE_ENTRY(T10, 10), TILE_ENTRY(T11, 11), TILE_ENTRY(T12, 12), TILE_ENTRY(T13, 13),
+                                    TILE_ENTRY(T14, 2)};
 
 // kernels whose staged epilogue needs more than the default 64 KiB of dynamic LDS
 bool raise_lds_limits() {
@@ -1449,12 +1530,21 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     HAWQ_REQUIRE(!a->in_planar, "hawq_conv2d: in_planar activations are read by the 3x3 band kernels only (tile %d is not one)", a->tile);
     HAWQ_REQUIRE(tile >= 0 && tile < NUM_TILES, "hawq_conv2d: bad tile id %d", a->tile);
     if (p.Cout % kTiles[tile].BN != 0) tile = 2;
-    if (kTiles[tile].ksub > 1) {  // K = 128 per barrier: int8 x int8 async pipeline with even chunk counts only
+    if (kTiles[tile].ksub > 1) {  // K = 128 (or more) per barrier: async pipeline with chunk counts the stage divides
         const int nk1 = a->KH * a->KW * (a->Cin >> 6), nk2 = dual ? (a->Cin2 >> 6) : 0;
         const bool all88 = a->in_bits == 8 && a->w_bits == 8 && (!dual || (a->in2_bits == 8 && a->w2_bits == 8));
         // (4/4 layers check the divisibility of their 128-channel chunk count inside the kernel and otherwise
-        //  run the register-staged loop, which works for any tile)
+        //  run the register-staged loop, which works for any tile without split-K)
         if (all88 && ((nk1 % kTiles[tile].ksub) || (nk2 % kTiles[tile].ksub))) tile = kTiles[tile].twin;
+        if (kTiles[tile].kg > 1) {   // split-K tiles exist on the asynchronous pipelines only
+            const bool all44 = a->in_bits == 4 && a->w_bits == 4 && (!dual || (a->in2_bits == 4 && a->w2_bits == 4));
+            const int ks = kTiles[tile].ksub;
+            const bool nib_ok = all44 && (a->Cin & 127) == 0 && (!dual || (a->Cin2 & 127) == 0) &&
+                                ((a->KH * a->KW * (a->Cin >> 7)) % ks) == 0 && (!dual || ((a->Cin2 >> 7) % ks) == 0);
+            const bool wide_res_ = a->epilogue == HAWQ_EPI_RESIDUAL && ((!dual && a->res_in_bits == 32) || (a->res_out && a->res_out_bits == 32));
+            const bool tables = a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL;
+            if (!(all88 || nib_ok) || wide_res_ || (tables && !fast)) tile = kTiles[tile].twin;
+        }
     }
     const TileInfo &ti = kTiles[tile];
     const int grid = ((p.M + ti.BM - 1) / ti.BM) * (p.Cout / ti.BN);
@@ -1476,7 +1566,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         const int stage_bytes = ti.lds / ti.ns;
         static const bool full_ring = getenv("HAWQ_FULL_RING") != nullptr;  // A/B switch for measurements
         if (!full_ring && all88 && fast && needs_tables && !wide_res && stages >= 1 && stages < ti.ns &&
-            stages * stage_bytes >= ti.BM * ti.BN)  // (the int8 output tile is staged on top of the ring)
+            stages * stage_bytes >= ti.BM * ti.BN * (ti.kg > 1 ? 4 : 1))  // (the int8 output tile - split-K: the partial sums - is staged on top of the ring)
             lds = stages * stage_bytes;
     }
     p.ring_bytes = lds;
