@@ -142,7 +142,8 @@ def validate(model, loader, uint8: bool = False, mean=(0.485, 0.456, 0.406), std
     """Top-1 / top-5 accuracy (percent) of a frozen ``Q_ResNet*`` over ``loader`` = iterable of (images, target):
     the body of the reference's ``validate()`` (freeze, eval, no_grad, ``accuracy(output, target, topk=(1, 5))``,
     sample-weighted averages).  ``images`` are normalised fp32 NCHW batches as the reference's pipeline produces, or -
-    ``uint8`` - raw uint8 NHWC batches that go through the look-up-table input quantiser (``forward_uint8``).
+    ``uint8`` - raw uint8 NHWC batches that go through the look-up-table input quantiser (``forward_uint8``);
+    ``hawq_amd.image.preprocess_batch`` turns decoded images of any size into such batches (Resize(256) + CenterCrop(224)).
     Returns (top1, top5, n_images)."""
     freeze_model(model)
     model.eval()

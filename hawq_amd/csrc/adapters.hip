@@ -215,3 +215,56 @@ extern "C" int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const in
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Image pipeline in front of forward_uint8 (quant_train.py:428-440: transforms.Resize(256) + CenterCrop(224) on the
+// decoded PIL image, then ToTensor + Normalize, which the stem's look-up table replays).  One separable pass of Pillow's
+// 8-bit antialiased resampling (libImaging/Resample.c, ImagingResampleHorizontal_8bpc / ...Vertical_8bpc): fixed-point
+// coefficients with 22 fractional bits, accumulator started at 2^21, result clipped to 0..255.  The coefficients are
+// computed on the host in binary64 exactly as precompute_coeffs + normalize_coeffs_8bpc do (hawq_amd/image.py).
+// uint8 HWC in and out; byte work, HBM-bound.
+namespace {
+__global__ void resample_u8_kernel(const uint8_t *__restrict__ in, int in_w, int C, const int32_t *__restrict__ bounds,
+                                   const int32_t *__restrict__ coef, int ksize, int out_n, int horizontal, int lines, int line0,
+                                   int out_w, uint8_t *__restrict__ out) {
+    // horizontal: out[l][o][c] over lines l (input rows line0 + l) and output columns o;  in [.][in_w][C]
+    // vertical:   out[o][x][c] over output rows o and columns x = l (line0 == 0);        in [.][in_w][C], in_w == out_w
+    const long long total = (long long)lines * out_n * C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        int l, o;
+        if (horizontal) {
+            o = (int)((idx / C) % out_n), l = (int)(idx / ((long long)C * out_n));
+        } else {
+            l = (int)((idx / C) % lines), o = (int)(idx / ((long long)C * lines));
+        }
+        const int k0 = bounds[2 * o], kn = bounds[2 * o + 1];
+        const int32_t *k = coef + (size_t)o * ksize;
+        int ss = 1 << 21;
+        if (horizontal) {
+            const uint8_t *row = in + ((size_t)(line0 + l) * in_w + k0) * C + c;
+            for (int x = 0; x < kn; ++x) ss += (int)row[(size_t)x * C] * k[x];
+            ss >>= 22;
+            out[((size_t)l * out_n + o) * C + c] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+        } else {
+            const uint8_t *col = in + ((size_t)k0 * in_w + l) * C + c;
+            for (int y = 0; y < kn; ++y) ss += (int)col[(size_t)y * in_w * C] * k[y];
+            ss >>= 22;
+            out[((size_t)o * out_w + l) * C + c] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+        }
+    }
+}
+}  // namespace
+
+extern "C" int hawq_resample_u8(const uint8_t *in, int32_t in_w, int32_t C, const int32_t *bounds, const int32_t *coef, int32_t ksize,
+                                int32_t out_n, int32_t horizontal, int32_t lines, int32_t line0, uint8_t *out, void *stream) {
+    HAWQ_REQUIRE(in && bounds && coef && out, "hawq_resample_u8: null pointer");
+    HAWQ_REQUIRE(in_w > 0 && C > 0 && ksize > 0 && out_n > 0 && lines > 0 && line0 >= 0, "hawq_resample_u8: bad geometry");
+    const long long total = (long long)lines * out_n * C;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_w, C, bounds, coef, ksize, out_n, horizontal,
+                       lines, line0, horizontal ? out_n : lines, out);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,102 @@
+"""Image pipeline in front of the uint8 input path (quant_train.py:428-440): ``transforms.Resize(256)`` and
+``transforms.CenterCrop(224)`` on the decoded image, on the MI355X; ``ToTensor`` + ``Normalize`` + the input QuantAct are
+the look-up table of ``IntegerEngine.forward_uint8``.
+
+torchvision's Resize on a PIL image is ``Image.resize(..., BILINEAR)``: Pillow's antialiased separable resampling
+(libImaging/Resample.c).  The coefficient construction below restates its ``precompute_coeffs`` (binary64, support scaled by
+the down-sampling factor, taps normalised to sum 1) and ``normalize_coeffs_8bpc`` (22 fractional bits, round half away);
+the two passes run in ``hawq_resample_u8``.  Pillow itself is not installable in the build container, so this stage is
+**parity-unpinned**: it is tested against ``oracle/pil_resample.py``, a numpy restatement of the same published algorithm,
+not against Pillow's output.  JPEG decoding stays on the host (any decoder that yields uint8 HWC).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def bilinear_coeffs(in_size: int, out_size: int):
+    """Resample.c: precompute_coeffs (bilinear filter, support 1.0) + normalize_coeffs_8bpc.
+    Returns (bounds int32 [out, 2] = (first input index, taps), coef int32 [out, ksize], ksize)."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.float64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        x = np.arange(xmax, dtype=np.float64)
+        w = np.abs((x + xmin - center + 0.5) * ss)
+        w = np.where(w < 1.0, 1.0 - w, 0.0)
+        ww = w.sum()
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :xmax] = w
+        bounds[xx] = (xmin, xmax)
+    coef = np.where(kk < 0, (-0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64), (0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64))
+    return bounds, coef.astype(np.int32), ksize
+
+
+def resize_crop_geometry(h: int, w: int, resize: int = 256, crop: int = 224):
+    """torchvision Resize(int) (smaller edge -> resize, other edge int(resize * long / short)) + CenterCrop(crop):
+    (resized h, resized w, crop top, crop left)."""
+    if w <= h:
+        ow, oh = resize, int(resize * h / w)
+    else:
+        oh, ow = resize, int(resize * w / h)
+    return oh, ow, int(round((oh - crop) / 2.0)), int(round((ow - crop) / 2.0))
+
+
+_COEFF_CACHE = {}
+
+
+def _coeffs_dev(in_size, out_size, lo, n, dev):
+    key = (in_size, out_size, lo, n, str(dev))
+    if key not in _COEFF_CACHE:
+        b, c, k = bilinear_coeffs(in_size, out_size)
+        _COEFF_CACHE[key] = (torch.from_numpy(np.ascontiguousarray(b[lo:lo + n])).to(dev), torch.from_numpy(np.ascontiguousarray(c[lo:lo + n])).to(dev), k,
+                             int(b[lo:lo + n, 0].min()), int((b[lo:lo + n, 0] + b[lo:lo + n, 1]).max()))
+    return _COEFF_CACHE[key]
+
+
+def resize_center_crop(img: torch.Tensor, resize: int = 256, crop: int = 224) -> torch.Tensor:
+    """uint8 HWC image on the MI355X -> uint8 [crop, crop, C], equal to CenterCrop(crop)(Resize(resize)(PIL image)) as
+    restated above.  Only the crop window is computed (same values: the passes are separable and local)."""
+    if not img.is_cuda or img.dtype != torch.uint8 or img.dim() != 3:
+        raise ValueError("expected a uint8 HWC tensor on the MI355X")
+    h, w, ch = img.shape
+    oh, ow, top, left = resize_crop_geometry(h, w, resize, crop)
+    if oh < crop or ow < crop:
+        raise ValueError("image too small for the crop (torchvision pads here; ImageNet validation images never need it)")
+    img = img.contiguous()
+    dev, sp = img.device, torch.cuda.current_stream(img.device).cuda_stream
+    bv, cv, kv, y0, y1 = _coeffs_dev(h, oh, top, crop, dev)       # vertical taps of the crop rows: input rows y0 .. y1
+    bh, chh, kh, _, _ = _coeffs_dev(w, ow, left, crop, dev)
+    # Pillow runs the horizontal pass first, on the input rows the vertical pass will read
+    tmp = torch.empty(y1 - y0, crop, ch, dtype=torch.uint8, device=dev)
+    if ow != w:
+        _lib.call("hawq_resample_u8", img.data_ptr(), w, ch, bh.data_ptr(), chh.data_ptr(), kh, crop, 1, y1 - y0, y0, tmp.data_ptr(), sp)
+    else:
+        tmp.copy_(img[y0:y1, left:left + crop])
+    if oh == h:
+        return tmp[top - y0:top - y0 + crop].clone()
+    out = torch.empty(crop, crop, ch, dtype=torch.uint8, device=dev)
+    bv_rel = bv.clone()
+    bv_rel[:, 0] -= y0   # tmp starts at input row y0
+    _lib.call("hawq_resample_u8", tmp.data_ptr(), crop, ch, bv_rel.data_ptr(), cv.data_ptr(), kv, crop, 0, crop, 0, out.data_ptr(), sp)
+    return out
+
+
+def preprocess_batch(images, resize: int = 256, crop: int = 224) -> torch.Tensor:
+    """List of decoded uint8 HWC images (any sizes, host or device) -> uint8 [N, crop, crop, C] for ``forward_uint8``."""
+    return torch.stack([resize_center_crop(im.cuda() if not im.is_cuda else im, resize, crop) for im in images])

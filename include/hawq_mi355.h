@@ -230,6 +230,15 @@ int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const int32_t *bias
                         int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t groups,
                         int32_t *out_acc, void *stream);
 
+/* One separable pass of Pillow's 8-bit antialiased resampling (what torchvision's Resize(256) does to the decoded PIL image,
+ * quant_train.py:428-440): uint8 HWC in / out, int32 coefficients with 22 fractional bits (hawq_amd/image.py builds them as
+ * Resample.c's precompute_coeffs + normalize_coeffs_8bpc do).
+ *   horizontal = 1: out[l][o][c], l < lines (input rows line0 + l), o < out_n output columns; in rows are in_w pixels wide
+ *   horizontal = 0: out[o][l][c], o < out_n output rows, l < lines columns (in_w == lines, line0 == 0)
+ * bounds[2o], bounds[2o+1] = first input index and number of taps of output o; coef[o * ksize + k]. */
+int hawq_resample_u8(const uint8_t *in, int32_t in_w, int32_t C, const int32_t *bounds, const int32_t *coef, int32_t ksize,
+                     int32_t out_n, int32_t horizontal, int32_t lines, int32_t line0, uint8_t *out, void *stream);
+
 /* ---- range statistics of the un-frozen QuantAct (calibration / QAT range tracking) -----------------
  * x.data.min(), x.data.max() (quant_modules.py:233-236) of a fp32 tensor -> out2[0], out2[1] (device floats).
  * scratch: >= 8 bytes of device memory owned by the caller for the duration of the call. */

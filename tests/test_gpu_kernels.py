@@ -713,3 +713,22 @@ def test_range_statistics_kernels_match_reference_kats(lib):
             got = np.array([float(a.x_min), float(a.x_max), float(s)], np.float32)
             assert np.array_equal(got, kx[f"act_{tag}_rng"][it]), (tag, it, got, kx[f"act_{tag}_rng"][it])
             assert np.array_equal(y.cpu().numpy(), kx[f"act_{tag}_y"][it]), (tag, it)
+
+
+def test_resize_center_crop_matches_the_restated_pillow_algorithm():
+    """hawq_amd.image.resize_center_crop (hawq_resample_u8, crop window only) vs the whole-image numpy restatement of Pillow's
+    antialiased bilinear resize + CenterCrop (oracle/pil_resample.py): landscape, portrait, up-scaling, identity axis."""
+    from hawq_amd.image import preprocess_batch, resize_center_crop
+    from oracle import pil_resample
+    rng = np.random.default_rng(0)
+    imgs = []
+    for h, w in ((375, 500), (500, 333), (256, 256), (200, 180), (256, 400), (1200, 900), (224, 224)):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        img[::7, ::5] = 255
+        img[3::11, 2::13] = 0
+        ref = pil_resample.resize_center_crop(img)
+        got = resize_center_crop(torch.from_numpy(img).cuda()).cpu().numpy()
+        assert got.shape == (224, 224, 3) and np.array_equal(got, ref), (h, w, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+        imgs.append(torch.from_numpy(img))
+    batch = preprocess_batch(imgs[:3])
+    assert batch.shape == (3, 224, 224, 3) and batch.dtype == torch.uint8 and batch.is_cuda

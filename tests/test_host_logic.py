@@ -246,3 +246,19 @@ def test_mobilenetv2_graph_and_schedules_line_up():
         assert sum(c.conv.groups > 1 for c in convs) == 17 and all(c.conv.groups == c.conv.in_channels for c in convs if c.conv.groups > 1)
         assert sum(isinstance(v, QuantAct) for v in mods.values()) == 2 + 17 * 4 + 3
         assert mods["features.stage4.unit5.conv2"].weight_bit == cfg["features.stage4.unit5.conv2"]
+
+
+def test_resize_coefficients_match_the_independent_restatement():
+    """hawq_amd.image.bilinear_coeffs (vectorised) vs oracle/pil_resample.py (scalar loops, written separately): bounds and
+    22-bit coefficients of Pillow's antialiased bilinear resize for down-, up- and identity scaling; taps sum to 2^22 +- taps."""
+    from hawq_amd.image import bilinear_coeffs, resize_crop_geometry
+    from oracle import pil_resample
+    for in_size, out_size in ((500, 256), (375, 256), (333, 341), (256, 256), (100, 256), (2000, 256), (257, 256)):
+        b, c, k = bilinear_coeffs(in_size, out_size)
+        ref = pil_resample._coeffs(in_size, out_size)
+        assert len(ref) == out_size
+        for o, (x0, ks) in enumerate(ref):
+            assert b[o, 0] == x0 and b[o, 1] == len(ks) and list(c[o, :len(ks)]) == ks and not c[o, len(ks):].any(), (in_size, out_size, o)
+            assert abs(int(c[o].sum()) - (1 << 22)) <= len(ks)
+    assert resize_crop_geometry(375, 500) == (256, 341, 16, 58) and resize_crop_geometry(500, 375) == (341, 256, 58, 16)
+    assert resize_crop_geometry(256, 256) == (256, 256, 16, 16)
