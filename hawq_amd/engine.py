@@ -92,7 +92,9 @@ class _Conv:
         self.stride, self.pad = int(mod.conv.stride[0]), int(mod.conv.padding[0])
         if mod.conv.groups != 1 or mod.conv.dilation[0] != 1:
             raise NotImplementedError("grouped/dilated convolutions are outside the ResNet hot path")
-        self.w_bits = 4 if mod.weight_bit <= 4 else 8
+        # storage of the weights follows the storage of the activations they meet (see IntegerEngine._storage): nibbles only
+        # for 4-bit x 4-bit layers, int8 otherwise - a 4-bit weight in an int8 byte is the same integer
+        self.w_bits = 4 if (mod.weight_bit <= 4 and in_bits == 4) else 8
         self.in_bits = in_bits
         self.s_w = mod.convbn_scaling_factor.detach().float().cpu()
         self.w_host = w_int
@@ -197,7 +199,7 @@ class IntegerEngine:
             d = dict(name=name, resize=bool(u.resize_identity), nb=u.n_body)
             qa = u.quant_act
             s_a = self._scale(qa)
-            d['a_bits'] = self._store_bits(qa)
+            d['a_bits'] = self._storage(self._store_bits(qa), [u.quant_convbn1] + ([u.quant_identity_convbn] if u.resize_identity else []))
             d['a_rng'] = _act_range(qa.activation_bit, qa.quant_mode)
             mq, eq = requant_table(s_prev, one, s_a, vbits=RES_VBITS)
             d['mq'], d['eq'] = int(mq[0]), int(eq[0])
@@ -214,7 +216,8 @@ class IntegerEngine:
                     act = getattr(u, f"quant_act{i}")
                     s_n = self._scale(act)
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
-                    ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=self._store_bits(act),
+                    ent.update(m=_i32(mm, dev), e=_i32(ee, dev),
+                               out_bits=self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")]),
                                rng=_act_range(act.activation_bit, act.quant_mode),
                                fast=tables_fit_fast(mm, ee, c.vbits), tie=not tables_are_fast(mm, ee, c.vbits),
                                k0=_no_preshift(ee))
@@ -278,6 +281,19 @@ class IntegerEngine:
                        bias=_i32(b, dev), fscale=torch.from_numpy(fscale).to(dev), nout=nout, nout_p=nout_p, k=k)
 
     @staticmethod
+    def _storage(value_bits, consumers):
+        """Storage width of an activation tensor whose VALUES are `value_bits` wide: hawq4 nibbles only if every conv that
+        reads it is a 4-bit x 4-bit layer the nibble pipelines take (Cin % 128 == 0: a 64-byte LDS row is 128 channels);
+        int8 otherwise.  Mixed-width layers (W4A8 / W8A4 of the latency_* / modelsize_* schedules) and the 64-channel
+        4-bit layers of stage 1 then run the int8 asynchronous pipelines, band kernels and fused launches instead of the
+        register-staged loop; the integers - hence every result - are the same, the tensor is at most 2x the bytes.
+        HAWQ_NATIVE_STORAGE=1 restores one nibble per 4-bit value everywhere (A/B measurements)."""
+        if value_bits != 4 or os.environ.get("HAWQ_NATIVE_STORAGE"):
+            return value_bits
+        ok = all(m.weight_bit <= 4 and m.conv.in_channels % 128 == 0 and m.conv.groups == 1 for m in consumers)
+        return 4 if ok else 8
+
+    @staticmethod
     def _store_bits(act):
         if act.activation_bit <= 4:
             if act.quant_mode != 'asymmetric':
@@ -318,13 +334,17 @@ class IntegerEngine:
             return None
         ent = nxt['convs'][0]
         c = ent['conv']
-        if not ent.get('fast', False) or ent['out_bits'] != 8 or nxt['a_bits'] != 8 or c.w_bits != 8:
+        if not ent.get('fast', False) or ent['out_bits'] != 8 or a.in_bits != 8 or a.w_bits != 8:
             return None
         er = _lib.ExpandReduceArgs()
         C.memmove(C.byref(er.expand), C.byref(a), C.sizeof(a))
-        er.expand.out_q = None   # the 8-bit block input of the next unit stays on chip
+        er.expand.out_q, er.expand.out_bits = None, 8   # the block input of the next unit stays on chip (its storage width is moot)
         r = er.reduce
-        r.wgt, r.bias = c.w.data_ptr(), c.bias.data_ptr()
+        if c.w_bits != 8 and not hasattr(c, "w8"):
+            # a 4-bit reduce conv whose input is stored as nibbles when it runs as its own launch: the fused launch reads
+            # the same integers from an int8 copy of its weights (the block input never takes a storage format at all)
+            c.w8 = torch.from_numpy(packing.pack_conv_weight(c.w_host, 8)).to(self.dev)
+        r.wgt, r.bias = (c.w if c.w_bits == 8 else c.w8).data_ptr(), c.bias.data_ptr()
         r.N, r.H, r.W, r.Cin, r.Cout, r.KH, r.KW, r.stride, r.pad = N, ho, wo, c.cin, c.cout, c.kh, c.kw, c.stride, c.pad
         r.in_bits, r.w_bits = 8, 8
         r.m, r.e, r.ctab = ent['m'].data_ptr(), ent['e'].data_ptr(), ent['ctab'].data_ptr()
@@ -340,11 +360,12 @@ class IntegerEngine:
         planar = self.planar and self._band_takes(nxt['convs'][1], N, ho, wo, 8, False, nxt)
         r.out_planar = int(planar)
         # the same two layers as separate launches (the block input q then goes through memory)
-        q = self._alloc(N * ho * wo * c.cin, torch.uint8)
+        q = self._alloc(N * ho * wo * c.cin * nxt['a_bits'] // 8, torch.uint8)
         a.out_q = q.data_ptr()
         r1 = _lib.ConvArgs()
         C.memmove(C.byref(r1), C.byref(r), C.sizeof(r1))
-        r1.in_ = q.data_ptr()
+        r1.in_, r1.in_bits = q.data_ptr(), nxt['a_bits']
+        r1.wgt, r1.w_bits = c.w.data_ptr(), c.w_bits
         pair = _FusedPair(er, a, r1, self.stream.cuda_stream)
         keep += [out, er, q, r1, pair]
         return pair, out, 8, planar
