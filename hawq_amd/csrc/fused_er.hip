@@ -26,7 +26,8 @@ namespace {
 
 struct ERP {
     const uint8_t *x2, *w3, *w1;
-    const int32_t *ctab3, *ctab1;
+    const uint8_t *xid, *wid;          // DUAL: input and weights of the unit's 1x1 identity conv (same pixels: stride 1, C channels)
+    const int32_t *ctab3, *ctab1, *ctab_id;
     const uint16_t *res_in;
     uint16_t *res_out;
     uint8_t *y;
@@ -49,21 +50,25 @@ __device__ __attribute__((aligned(16))) const int g_er_zero16[4] = {0, 0, 0, 0};
 // RESDMA: the old residual slice is prefetched one slice ahead into LDS by the producers (memory-bound stage 1: the
 // HBM latency needs a whole slice of cover); otherwise each compute lane loads its 32 bytes straight into registers at
 // the top of the slice (L2 / Infinity-Cache resident in the later stages; 16 KiB less LDS, more workgroups per CU).
-template <int C_, int WM_, int NP_, bool RESDMA_, int MINB_>
+// DUAL: the first unit of a stage whose identity branch is a 1x1 / stride-1 conv over the same pixels (ResNet50 stage 1):
+// the identity conv is a second GEMM1 (its own resident input tile, its weight slice in the same ring stage as W3's) and its
+// requantised accumulators take the place of the stored residual (q_resnet.py:236-251).
+template <int C_, int WM_, int NP_, bool RESDMA_, int MINB_, bool DUAL_ = false>
 struct ERCfg {
     static constexpr int C = C_, WM = WM_, NP = NP_, MINB = MINB_;
-    static constexpr bool RESDMA = RESDMA_;
+    static constexpr bool RESDMA = RESDMA_, DUAL = DUAL_;
     static constexpr int BM = 32 * WM, NW = 2 * WM, NTC = 64 * NW, NT = NTC + 64 * NP;
     static constexpr int NI = NP > 0 ? NP : NW, NPT = 64 * NI;   // waves / threads that issue LDS-DMA (NP == 0: the compute waves themselves)
     static constexpr int KC = C / 64;          // 64-byte chunks of GEMM1's K
     static constexpr int CT2 = C / 64;         // 32-channel MFMA tiles per wave in GEMM2 (2 waves across the C channels)
     static constexpr int RPP = NPT / 4;        // operand rows per producer LDS-DMA pass (4 lanes x 16 B per 64-byte row)
     static constexpr int NSW = 3;
-    static constexpr int WSTAGE = 64 * C;      // W3 slice [KC][64 rows][64 B]  ==  W1 slice [C rows][64 B]
+    static constexpr int WSTAGE = (DUAL ? 2 : 1) * 64 * C;   // W3 slice [KC][64 rows][64 B] (+ identity slice)  >=  W1 slice [C rows][64 B]
+    static constexpr int W1PASS = 64 * C / (RPP * 64);        // LDS-DMA instructions per thread of a W1 slice
     static constexpr int WPASS = WSTAGE / (RPP * 64);   // LDS-DMA instructions per producer thread per ring stage
     static constexpr int XPASS = BM / RPP;     // per 64-byte chunk of the x2 tile
     static constexpr int RPASS = BM * 8 / NPT; // residual slice: BM rows x 8 chunks of 16 B
-    static constexpr int X2_BYTES = BM * C;
+    static constexpr int X2_BYTES = (DUAL ? 2 : 1) * BM * C;   // resident input tile(s): x2 (+ the identity conv's input)
     static constexpr int Q_BYTES = BM * 64, RES_BYTES = BM * 128;
     // LDS map.  q is single-buffered: written between B1(j) and B2(j), read between B2(j) and B1(j+1); so is the residual
     // staging tile unless it doubles as the prefetch target (RESDMA: in place, two buffers)
@@ -71,8 +76,9 @@ struct ERCfg {
     static constexpr int OFF_RING = OFF_X2 + X2_BYTES;
     static constexpr int OFF_Q = OFF_RING + NSW * WSTAGE;       // [BM][64 B]
     static constexpr int OFF_RES = OFF_Q + Q_BYTES;             // [1 or 2][BM][64] uint16
-    static constexpr int OFF_CT3 = OFF_RES + (RESDMA ? 2 : 1) * RES_BYTES;   // [2][64][16 B]
-    static constexpr int LDS_BYTES = OFF_CT3 + 2 * 1024;
+    static constexpr int OFF_CT3 = OFF_RES + (RESDMA ? 2 : 1) * RES_BYTES;   // [2][64][16 B] (DUAL: + the identity conv's)
+    static constexpr int LDS_BYTES = OFF_CT3 + (DUAL ? 4 : 2) * 1024;
+    static_assert(!(DUAL && RESDMA), "a dual-branch unit has no stored residual to prefetch");
     static_assert(WSTAGE % (RPP * 64) == 0 && BM % RPP == 0 && (BM * 8) % NPT == 0 && C % RPP == 0 && (RPP & 15) == 0,
                   "tiles must fill whole producer passes");
     static_assert(BM * C <= NSW * WSTAGE, "the output tile is staged on the weight ring");
@@ -119,24 +125,28 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
     const int prow = pt >> 2, pslot = pt & 3;
     const int sw = (pslot ^ ((prow >> 2) & 3)) << 4;   // source-side swizzle of this thread's 16-byte slot (same for rows prow + k * RPP)
     const char *zero = reinterpret_cast<const char *>(g_er_zero16);
-    auto issue_w3 = [&](int j, int stage) {   // rows j*64 .. j*64+63 of W3 [C3][C], as KC chunks of [64 rows][64 B]
+    auto issue_w3 = [&](int j, int stage) {   // rows j*64 .. j*64+63 of W3 [C3][C], as KC chunks of [64 rows][64 B] (+ identity weights)
         char *dst = ring + stage * F::WSTAGE + pw * 1024;
 #pragma unroll
-        for (int i = 0; i < F::WPASS; ++i) {
+        for (int i = 0; i < F::W1PASS; ++i) {
             const int idx = i * F::RPP + prow, chunk = idx >> 6, row = idx & 63;
             dma16((const char *)p.w3 + (size_t)(j * 64 + row) * F::C + chunk * 64 + sw, dst + i * (F::RPP * 64));
+            if constexpr (F::DUAL)
+                dma16((const char *)p.wid + (size_t)(j * 64 + row) * F::C + chunk * 64 + sw, dst + 64 * F::C + i * (F::RPP * 64));
         }
     };
     auto issue_w1 = [&](int j, int stage) {   // columns j*64 .. j*64+63 of W1 [C][C3], as [C rows][64 B]
         char *dst = ring + stage * F::WSTAGE + pw * 1024;
 #pragma unroll
-        for (int i = 0; i < F::WPASS; ++i) {
+        for (int i = 0; i < F::W1PASS; ++i) {
             const int row = i * F::RPP + prow;
             dma16((const char *)p.w1 + (size_t)row * p.C3 + j * 64 + sw, dst + i * (F::RPP * 64));
         }
     };
     auto issue_grp = [&](int j) {   // ctab3 slice: 4 x 256 B (issuing waves beyond the 4th repeat); residual slice if RESDMA
         dma4((const char *)p.ctab3 + (size_t)j * 1024 + (pw & 3) * 256 + lane * 4, ct3 + (j & 1) * 1024 + (pw & 3) * 256);
+        if constexpr (F::DUAL)
+            dma4((const char *)p.ctab_id + (size_t)j * 1024 + (pw & 3) * 256 + lane * 4, ct3 + 2048 + (j & 1) * 1024 + (pw & 3) * 256);
         if constexpr (F::RESDMA) {
             char *dst = rest + (j & 1) * F::RES_BYTES;
 #pragma unroll
@@ -156,13 +166,16 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 const int row = i * F::RPP + prow;
                 dma16(m0 + row < p.M ? (const char *)p.x2 + (size_t)(m0 + row) * F::C + kc * 64 + sw : zero,
                       x2t + kc * (F::BM * 64) + i * (F::RPP * 64) + pw * 1024);
+                if constexpr (F::DUAL)
+                    dma16(m0 + row < p.M ? (const char *)p.xid + (size_t)(m0 + row) * F::C + kc * 64 + sw : zero,
+                          x2t + F::BM * F::C + kc * (F::BM * 64) + i * (F::RPP * 64) + pw * 1024);
             }
         issue_w3(0, 0);
         issue_grp(0);
         issue_w1(0, 1);
-        wait_vmcnt<F::WPASS>();   // everything but W1(0) has landed
+        wait_vmcnt<F::W1PASS>();   // everything but W1(0) has landed
     };
-    constexpr int N_A = F::WPASS + 1 + (F::RESDMA ? F::RPASS : 0);   // instructions per thread of one {W3, ctab3, residual} group
+    constexpr int N_A = F::WPASS + (F::DUAL ? 2 : 1) + (F::RESDMA ? F::RPASS : 0);   // instructions per thread of one {W3 (+ identity), ctab3, residual} group
     if (F::NP > 0 && producer) {
         // ------------------------------------------------------------ producer waves: all LDS-DMA, nothing else
         issue_prologue();
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
             __builtin_amdgcn_s_barrier();   // B2(j)
             if (j + 1 < nslices) {
                 issue_w1(j + 1, (2 * j + 3) % 3);   // the stage GEMM1(j) read
-                wait_vmcnt<F::WPASS>();             // the {W3, ctab3, residual}(j+1) group has landed (no stores here: counts are exact)
+                wait_vmcnt<F::W1PASS>();            // the {W3, ctab3, residual}(j+1) group has landed (no stores here: counts are exact)
             }
         }
         __syncthreads();
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
         // !RESDMA: this lane's 16 residual values of slice j (32 contiguous bytes) straight into registers.  Hand-issued
         // and waited for (the only younger memory operations of a compute wave are none; its stores are older)
         v4i rin[2];
-        if constexpr (!F::RESDMA) {
+        if constexpr (!F::RESDMA && !F::DUAL) {
             const char *rp = (const char *)p.res_in + ((size_t)res_row * p.C3 + j * 64 + lch) * 2;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rin[0]) : "v"(rp) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rin[1]) : "v"(rp) : "memory");
@@ -221,9 +234,9 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
             }
         ER_STAMP(2)
         // ------------------------------------------------------------ GEMM1
-        v16i acc1;
+        v16i acc1, acc_id;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0;
+        for (int r = 0; r < 16; ++r) acc1[r] = 0, acc_id[r] = 0;
         {
             const char *w3s = ring + st3 * F::WSTAGE;
 #pragma unroll
@@ -233,6 +246,11 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                     const v4i wf = *reinterpret_cast<const v4i *>(w3s + kc * 4096 + lds_off(wrow1, 2 * ks + h));
                     const v4i af = *reinterpret_cast<const v4i *>(x2t + kc * (F::BM * 64) + lds_off(arow, 2 * ks + h));
                     acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc1, 0, 0, 0);
+                    if constexpr (F::DUAL) {
+                        const v4i wi = *reinterpret_cast<const v4i *>(w3s + 64 * F::C + kc * 4096 + lds_off(wrow1, 2 * ks + h));
+                        const v4i ai = *reinterpret_cast<const v4i *>(x2t + F::BM * F::C + kc * (F::BM * 64) + lds_off(arow, 2 * ks + h));
+                        acc_id = __builtin_amdgcn_mfma_i32_32x32x32_i8(wi, ai, acc_id, 0, 0, 0);
+                    }
                 }
         }
         ER_STAMP(3)
@@ -240,7 +258,11 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
         {
             char *rb = rest + (F::RESDMA ? (j & 1) * F::RES_BYTES : 0) + arow * 128;
             const char *ctb = ct3 + (j & 1) * 1024;
-            if constexpr (F::RESDMA) {
+            if constexpr (F::DUAL) {
+                if constexpr (F::NP == 0) {   // W1(j) must have landed before B2; nothing else to wait for here
+                    if (j + 1 < nslices) wait_vmcnt<N_A>(); else wait_vmcnt<0>();
+                }
+            } else if constexpr (F::RESDMA) {
                 rin[0] = *reinterpret_cast<const v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4));
                 rin[1] = *reinterpret_cast<const v4i *>(rb + ((((lch >> 3) + 1) ^ (arow & 7)) << 4));
             } else {
@@ -251,14 +273,18 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
             int rpack[8], qpack[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const unsigned w0 = (unsigned)rin[g >> 1][(g & 1) * 2], w1 = (unsigned)rin[g >> 1][(g & 1) * 2 + 1];
-                const int idin[4] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+                int idin[4];
+                if constexpr (!F::DUAL) {
+                    const unsigned w0 = (unsigned)rin[g >> 1][(g & 1) * 2], w1 = (unsigned)rin[g >> 1][(g & 1) * 2 + 1];
+                    idin[0] = (int)(w0 & 0xffffu), idin[1] = (int)(w0 >> 16), idin[2] = (int)(w1 & 0xffffu), idin[3] = (int)(w1 >> 16);
+                }
                 int o[4], qv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const DyNt dm = ctab_entry(ctb, lch + 4 * g + k);
                     const int a = dyadic_mode<MODE>(acc1[4 * g + k], dm);
-                    const int b = dyadic_mode<MODE>(idin[k], dids);
+                    const int b = F::DUAL ? dyadic_mode<MODE>(acc_id[4 * g + k], ctab_entry(ctb + 2048, lch + 4 * g + k))
+                                          : dyadic_mode<MODE>(idin[k], dids);
                     o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
                     qv[k] = min(dyadic_mode<MODE>(o[k], dq), p.q_hi);      // o >= 0, m >= 0: q >= 0
                 }
@@ -363,29 +389,38 @@ using E128D = ERCfg<128, 2, 0, true, 3>;    //          residual prefetched into
 using E128P = ERCfg<128, 2, 4, true, 4>;    //          4 + 4 waves (producers own the LDS-DMA), two workgroups per CU
 using E256 = ERCfg<256, 4, 0, false, 2>;    // stage 3: 128 pixels, 8 waves, 106 KiB, one workgroup per CU
 using E256P = ERCfg<256, 4, 4, true, 3>;    //          8 + 4 waves, residual prefetched into LDS, 122 KiB
-constexpr int NUM_ER = 7;
+using E64D = ERCfg<64, 2, 0, false, 4, true>;   // stage 1, first unit: identity conv as a second GEMM1, 46 KiB
+constexpr int NUM_ER = 8;
 
 typedef void (*ERFn)(const ERP);
-struct ERInfo { ERFn fn[2]; int c, bm, nt, lds; };
-#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>}, F::C, F::BM, F::NT, F::LDS_BYTES}
-const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P)};
+struct ERInfo { ERFn fn[2]; int c, bm, nt, lds; bool dual; };
+#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::DUAL}
+const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P), ER_ENTRY(E64D)};
 
-bool conv_is_1x1_int8_fast(const hawq_conv_args &a) {
-    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 && !a.in2 &&
-           !a.in_planar;
+bool conv_is_1x1_int8_fast(const hawq_conv_args &a, bool dual_ok = false) {
+    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 &&
+           (dual_ok || !a.in2) && !a.in_planar;
+}
+
+// the expand conv carries a second (identity) branch the dual variant can take: 1x1 / stride 1 over the same pixels, same channel count
+bool dual_branch_fits(const hawq_conv_args &e) {
+    return e.in2 && e.wgt2 && e.ctab_id && e.Cin2 == e.Cin && e.stride2 == 1 && e.H2 == e.H && e.W2 == e.W && e.in2_bits == 8 && e.w2_bits == 8;
 }
 
 // variant index (into kER) for this pair, or -1.  `tile` 0 = default, 1.. = the variants that take channel count C in table order
 int er_variant(const hawq_expand_reduce_args *a) {
     const hawq_conv_args &e = a->expand, &r = a->reduce;
-    if (!conv_is_1x1_int8_fast(e) || !conv_is_1x1_int8_fast(r)) return -1;
+    if (!conv_is_1x1_int8_fast(e, true) || !conv_is_1x1_int8_fast(r)) return -1;
+    const bool dual = e.in2 != nullptr;
+    if (dual && !dual_branch_fits(e)) return -1;
     if (e.epilogue != HAWQ_EPI_RESIDUAL || r.epilogue != HAWQ_EPI_REQUANT) return -1;
-    if (!e.res_in || e.res_in_bits != 16 || !e.res_out || e.res_out_bits != 16 || !e.flags || !e.ctab || !r.ctab || !r.out_q) return -1;
+    if (!dual && (!e.res_in || e.res_in_bits != 16)) return -1;
+    if (!e.res_out || e.res_out_bits != 16 || !e.flags || !e.ctab || !r.ctab || !r.out_q) return -1;
     if (r.out_bits != 8 || e.out_bits != 8) return -1;
     if (r.Cin != e.Cout || r.Cout != e.Cin || r.N != e.N || r.H != e.H || r.W != e.W || e.Cout % 64) return -1;
     int nth = 0, first = -1;
     for (int i = 0; i < NUM_ER; ++i)
-        if (kER[i].c == e.Cin) {
+        if (kER[i].c == e.Cin && kER[i].dual == dual) {
             if (first < 0) first = i;
             if (++nth == a->tile) return i;
         }
@@ -400,7 +435,7 @@ extern "C" int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *a
     q.tile = 0;
     if (er_variant(&q) < 0) return 0;
     int n = 0;
-    for (int i = 0; i < NUM_ER; ++i) n += kER[i].c == a->expand.Cin;
+    for (int i = 0; i < NUM_ER; ++i) n += kER[i].c == a->expand.Cin && kER[i].dual == (a->expand.in2 != nullptr);
     return n;
 }
 
@@ -408,20 +443,21 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     HAWQ_REQUIRE(a != nullptr, "hawq_conv_expand_reduce: null args");
     const int v = er_variant(a);
     HAWQ_REQUIRE(v >= 0, "hawq_conv_expand_reduce: this pair of layers cannot be fused (need 1x1/stride-1 int8 fast-contract convs, "
-                         "uint16 residual in and out, Cin in {64,128,256}, reduce.Cin == expand.Cout, reduce.Cout == expand.Cin; tile %d)", a->tile);
+                         "uint16 residual in and out - or a same-shape 1x1 identity branch with Cin 64 -, Cin in {64,128,256}, reduce.Cin == expand.Cout, reduce.Cout == expand.Cin; tile %d)", a->tile);
     const hawq_conv_args &e = a->expand, &r = a->reduce;
     auto e_fast = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62; };
-    HAWQ_REQUIRE(e.mq >= 0 && e_fast(e.eq) && e.m_id_scalar >= 0 && e_fast(e.e_id_scalar), "hawq_conv_expand_reduce: scalar tables outside the fast contract");
+    HAWQ_REQUIRE(e.mq >= 0 && e_fast(e.eq) && (e.in2 || (e.m_id_scalar >= 0 && e_fast(e.e_id_scalar))), "hawq_conv_expand_reduce: scalar tables outside the fast contract");
     HAWQ_REQUIRE(e.q_lo <= 0, "hawq_conv_expand_reduce: the block-input QuantAct clamp must admit 0");
     ERP p;
     p.x2 = (const uint8_t *)e.in, p.w3 = (const uint8_t *)e.wgt, p.w1 = (const uint8_t *)r.wgt;
     p.ctab3 = e.ctab, p.ctab1 = r.ctab;
+    p.xid = (const uint8_t *)e.in2, p.wid = (const uint8_t *)e.wgt2, p.ctab_id = e.ctab_id;
     p.res_in = (const uint16_t *)e.res_in, p.res_out = (uint16_t *)e.res_out;
     p.y = (uint8_t *)r.out_q;
     const long long M = (long long)e.N * e.H * e.W;
     HAWQ_REQUIRE(M > 0 && M < (1ll << 30), "hawq_conv_expand_reduce: bad problem size");
     p.M = (int)M, p.C3 = e.Cout;
-    p.m_id_s = e.m_id_scalar, p.e_id_s = e.e_id_scalar, p.mq = e.mq, p.eq = e.eq, p.q_hi = e.q_hi;
+    p.m_id_s = e.in2 ? 0 : e.m_id_scalar, p.e_id_s = e.in2 ? 33 : e.e_id_scalar, p.mq = e.mq, p.eq = e.eq, p.q_hi = e.q_hi;
     p.y_lo = r.relu && r.q_lo < 0 ? 0 : r.q_lo, p.y_hi = r.q_hi;
     p.y_planar = r.out_planar;
     p.flags = e.flags;

@@ -328,7 +328,7 @@ class IntegerEngine:
     def _try_fuse(self, a, u, nxt, N, ho, wo, keep):
         """Expand conv launch `a` of unit `u` (RESIDUAL epilogue, already filled) + reduce conv of unit `nxt`:
         returns (ExpandReduceArgs, output tensor, out_bits, planar) or None if the library does not take the pair."""
-        if nxt is None or nxt['resize'] or u['resize'] or len(nxt['convs']) != 3 or not a.fast_tables:
+        if nxt is None or nxt['resize'] or len(nxt['convs']) != 3 or not a.fast_tables:
             return None
         if int(u['name'].split('.')[0][len('stage'):]) not in self.fuse_stages:
             return None

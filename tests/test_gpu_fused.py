@@ -15,7 +15,7 @@ from tests.test_gpu_kernels import dev, from_planar, lib, make_conv, nhwc, odyad
 pytestmark = pytest.mark.gpu
 
 
-def _case(lib, orc, n, h, w, c, c3, seed, force_tie=False):
+def _case(lib, orc, n, h, w, c, c3, seed, force_tie=False, dual=False):
     from hawq_amd.packing import pack_conv_weight, pack_ctab
     from hawq_amd.quant_utils import requant_table, tables_are_fast, tables_fit_fast
     rng = np.random.default_rng(seed)
@@ -28,7 +28,19 @@ def _case(lib, orc, n, h, w, c, c3, seed, force_tie=False):
     m_id, e_id = requant_table(torch.tensor([0.37 * 0.7]), torch.ones(1), torch.tensor([0.7]))
     if force_tie:  # ratio 3/16 on channel 1: exact .5 ties whenever acc = 8 mod 16 -> the exact-tie kernels
         m3[1], e3[1] = 3 << 29, 34
-    o = np.maximum(odyadic(orc, acc3, m3, e3) + odyadic(orc, res, m_id, e_id), 0)
+    if dual:  # first unit of a stage: the identity branch is a 1x1 conv over the unit's own input (q_resnet.py:236-251)
+        xid, wid, bid = make_conv(rng, n, h, w, c, c3, 1, 8, 8)
+        xid = np.maximum(xid, 0)
+        acc_id = orc.conv2d(xid, wid, bid, 1, 0)
+        sdi = float(acc_id.std())
+        mi, ei = rand_tables(rng, c3, 500 / sdi, 4000 / sdi)
+        if force_tie:
+            mi[2], ei[2] = 5 << 28, 35
+        assert tables_fit_fast(mi, ei, int(np.abs(acc_id).max()).bit_length() + 1)
+        ident = odyadic(orc, acc_id, mi, ei)
+    else:
+        ident = odyadic(orc, res, m_id, e_id)
+    o = np.maximum(odyadic(orc, acc3, m3, e3) + ident, 0)
     assert o.max() < 65536
     mq, eq = requant_table(torch.tensor([0.0041 * 0.7]), torch.ones(1), torch.tensor([0.7]))
     q = odyadic(orc, o, mq, eq, (0, 127))
@@ -53,7 +65,14 @@ def _case(lib, orc, n, h, w, c, c3, seed, force_tie=False):
     ex.N, ex.H, ex.W, ex.Cin, ex.Cout, ex.KH, ex.KW, ex.stride, ex.pad = n, h, w, c, c3, 1, 1, 1, 0
     ex.in_bits, ex.w_bits, ex.epilogue = 8, 8, lib.EPI_RESIDUAL
     ex.m, ex.e, ex.ctab, ex.flags = keep['m3'].data_ptr(), keep['e3'].data_ptr(), keep['ctab3'].data_ptr(), keep['flags'].data_ptr()
-    ex.res_in, ex.res_in_bits, ex.m_id_scalar, ex.e_id_scalar = keep['res'].data_ptr(), 16, int(m_id[0]), int(e_id[0])
+    if dual:
+        keep.update(xid=dev(nhwc(xid).astype(np.int8).view(np.uint8)), wid=dev(pack_conv_weight(wid, 8)), bid=dev(bid.astype(np.int32)),
+                    mi=dev(mi), ei=dev(ei), ctab_id=dev(pack_ctab(bid, mi, ei)))
+        ex.in2, ex.wgt2, ex.bias2 = keep['xid'].data_ptr(), keep['wid'].data_ptr(), keep['bid'].data_ptr()
+        ex.H2, ex.W2, ex.Cin2, ex.stride2, ex.in2_bits, ex.w2_bits = h, w, c, 1, 8, 8
+        ex.m_id, ex.e_id, ex.ctab_id = keep['mi'].data_ptr(), keep['ei'].data_ptr(), keep['ctab_id'].data_ptr()
+    else:
+        ex.res_in, ex.res_in_bits, ex.m_id_scalar, ex.e_id_scalar = keep['res'].data_ptr(), 16, int(m_id[0]), int(e_id[0])
     ex.res_out, ex.res_out_bits = keep['res_out'].data_ptr(), 16
     ex.out_bits, ex.q_lo, ex.q_hi, ex.mq, ex.eq = 8, 0, 127, int(mq[0]), int(eq[0])
     ex.fast_tables = 1 if fast else 5
@@ -86,6 +105,33 @@ def test_expand_reduce_matches_oracle(lib, orc, shape, tie):
             assert keep['flags'].item() == 0
     a.tile = nvar + 1
     assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 14, 64, 256), (5, 7, 7, 64, 128), (1, 3, 5, 64, 64), (16, 56, 56, 64, 256)])
+@pytest.mark.parametrize("tie", [False, True])
+def test_expand_reduce_dual_branch(lib, orc, shape, tie):
+    """First unit of a stage with a stride-1 1x1 identity conv (ResNet50 stage 1): conv3 and the identity conv are
+    requantised separately (each with its own per-channel table), summed un-clamped, ReLU'd - then as above.  Also: the
+    same launch through hawq_conv2d (the separate dual-branch kernel) writes the same residual."""
+    n, h, w, c, c3 = shape
+    a, keep, o, y = _case(lib, orc, n, h, w, c, c3, zlib.crc32(repr(shape).encode()) + 1, force_tie=tie, dual=True)
+    nvar = lib.load().hawq_conv_expand_reduce_variants(C.byref(a))
+    assert nvar >= 1
+    for tile in range(0, nvar + 1):
+        a.tile = tile
+        keep['res_out'].zero_(), keep['y'].zero_()
+        lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+        got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+        assert np.array_equal(got, o), tile
+        assert np.array_equal(unpack_q(keep['y'], (n, h, w, c), 8), y), tile
+        assert keep['flags'].item() == 0
+    keep['res_out'].zero_()
+    a.expand.tile = 0
+    lib.call("hawq_conv2d", C.byref(a.expand), stream())
+    got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+    assert np.array_equal(got, o)
+    a.expand.stride2 = 2   # a strided identity conv reads other pixels: not this kernel's case
+    assert lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) == 0 and lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
 
 
 def test_expand_reduce_full_size_and_refusals(lib, orc):
