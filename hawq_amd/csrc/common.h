@@ -139,3 +139,25 @@ __device__ __forceinline__ int pack2_u16_sat(int a, int b) {
     const u2 r = __builtin_amdgcn_cvt_pk_u16((unsigned)a, (unsigned)b);
     return __builtin_bit_cast(int, r);
 }
+
+// Hand-issued LDS fragment reads.  hipcc treats every LDS-DMA instruction as a pending FLAT access and from then
+// on only ever emits `s_waitcnt lgkmcnt(0)` (measured on a toy kernel: lgkmcnt(2) without, lgkmcnt(0) with one
+// global_load_lds in the loop), so compiler-visible ds_reads cannot be software-pipelined in these kernels.
+// Reads issued through lds_read16 are invisible to its bookkeeping: the caller waits with wait_lgkm<N>() (N =
+// reads allowed to stay in flight; LDS returns in order, and a scalar load that happens to be in flight can
+// only make the wait stricter, never too lax, as long as N counts LDS reads issued AFTER the ones needed) and
+// then passes every fragment through pin() before its first use.
+template <int OFF>
+__device__ __forceinline__ v4i lds_read16(unsigned addr) {
+    v4i r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pin(v4i &f) { asm volatile("" : "+v"(f)); }
+__device__ __forceinline__ unsigned lds_addr(const char *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}

@@ -243,28 +243,6 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
 __device__ __attribute__((aligned(16))) const int g_zero16[4] = {0, 0, 0, 0};
 
 
-// Hand-issued LDS fragment reads.  hipcc treats every LDS-DMA instruction as a pending FLAT access and from then
-// on only ever emits `s_waitcnt lgkmcnt(0)` (measured on a toy kernel: lgkmcnt(2) without, lgkmcnt(0) with one
-// global_load_lds in the loop), so compiler-visible ds_reads cannot be software-pipelined in these kernels.
-// Reads issued through lds_read16 are invisible to its bookkeeping: the caller waits with wait_lgkm<N>() (N =
-// reads allowed to stay in flight; LDS returns in order, and a scalar load that happens to be in flight can
-// only make the wait stricter, never too lax, as long as N counts LDS reads issued AFTER the ones needed) and
-// then passes every fragment through pin() before its first use.
-template <int OFF>
-__device__ __forceinline__ v4i lds_read16(unsigned addr) {
-    v4i r;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void pin(v4i &f) { asm volatile("" : "+v"(f)); }
-__device__ __forceinline__ unsigned lds_addr(const char *p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
-}
-
 // NIB: both operands are hawq4 nibble-packed.  A ring-stage row still holds 64 BYTES (= 128 channels), the
 // packed bytes travel through LDS untouched and every fragment (8 B = 16 channels per lane) is unpacked to
 // int8 in registers right before its MFMA (activations zero-extended, weights as value*16 with the
@@ -1374,8 +1352,12 @@ int pick_tile(int M, int Cout, bool dual) {
 
 }  // namespace
 
-extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES; }  // the 3x3 band kernels are the last ids
-extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES; }
+// band_persist.hip: weight-stationary persistent 3x3 kernel for Cin == Cout == 64 (the id after the band tiles)
+bool band_persist_applies(const hawq_conv_args *a);
+int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs_per_cu, void *stream);
+
+extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES + 2; }  // the 3x3 band kernels are the last ids
+extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES + 2; }  // + the weight-stationary kernel of band_persist.hip with 1 / 2 workgroups per CU
 
 extern "C" int hawq_conv2d_band_tile(const hawq_conv_args *a) {
     if (!a || a->W <= 0 || a->H <= 0 || a->Cin <= 0 || a->Cout <= 0) return 0;
@@ -1500,6 +1482,10 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         for (int k = 0; k < NUM_BAND_TILES && tile < 0; ++k)
             if (band_applies(kBand[kBandPreference[k]], a)) tile = NUM_TILES + kBandPreference[k];
         HAWQ_REQUIRE(tile >= 0, "hawq_conv2d: in_planar input but no 3x3 band kernel takes this layer");
+    }
+    if (tile == NUM_TILES + NUM_BAND_TILES || tile == NUM_TILES + NUM_BAND_TILES + 1) {
+        HAWQ_REQUIRE(band_persist_applies(a), "hawq_conv2d: tile %d (weight-stationary 3x3 kernel) does not apply to this layer", a->tile);
+        return band_persist_launch(a, p.k0 == 2, p.dbg, tile - (NUM_TILES + NUM_BAND_TILES) + 1, stream);
     }
     if (tile >= NUM_TILES && tile < NUM_TILES + NUM_BAND_TILES) {
         // 3x3 band kernels (LDS-resident input band shared by the 9 taps): fast-contract int8 / hawq4 layers only

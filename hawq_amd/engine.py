@@ -431,6 +431,9 @@ class IntegerEngine:
                 self.subs.append(sub)
                 b0 = b1
             self._ops, self._keep, self._batch, self._graph = _OpList(), [], (N, H, W), None
+            if (self.autotune and not os.environ.get("HAWQ_TILES") and os.environ.get("HAWQ_JOINT_TUNE", "1") != "0"
+                    and all(hasattr(sub, "_tile_times") for sub in self.subs)):
+                self._autotune_joint()
             self.n_fast, self.n_conv, self.n_k0, self.n_tie = (self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0,
                                                               self.subs[0].n_tie)
             self.tile_choice, self.er_choice = self.subs[0].tile_choice, self.subs[0].er_choice
@@ -637,6 +640,7 @@ class IntegerEngine:
         shape, before the hipGraph is captured: ~50 launches x 4 tiles x reps, a few milliseconds."""
         n_tiles = _lib.load().hawq_conv2d_num_tiles()
         sp = self.stream.cuda_stream
+        self._tile_times, self._er_times = {}, {}
         e0, e1 = C.c_void_p(), C.c_void_p()
         _lib.call("hawq_event_create", C.byref(e0))
         _lib.call("hawq_event_create", C.byref(e1))
@@ -679,6 +683,7 @@ class IntegerEngine:
                             continue
                         times[tile] = min(times.get(tile, ms.value), ms.value)
                 best_t = min(times, key=times.get)
+                self._tile_times[name] = dict(times)
                 log = [f"{t}:{v / reps * 1e3:.1f}" for t, v in times.items()]
                 if os.environ.get("HAWQ_AUTOTUNE_LOG"):
                     print(f"[autotune N={a.N}] {name}: best {best_t}  us per tile: {' '.join(log)}", file=sys.stderr)
@@ -727,6 +732,7 @@ class IntegerEngine:
                         _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
                         times[tile] = min(times.get(tile, ms.value), ms.value)
                 er.tile = min(times, key=times.get)
+                self._er_times[name] = dict(times)
                 te, ms_e = best_tile(pair.expand)
                 tr, ms_r = best_tile(pair.reduce)
                 pair.expand.tile, pair.reduce.tile = te, tr
@@ -743,6 +749,89 @@ class IntegerEngine:
         _lib.call("hawq_event_destroy", e1)
         torch.cuda.synchronize(self.dev)
         self.flags.zero_()  # tuning launches ran on whatever the buffers held; only real forwards may raise the flag
+
+    def _autotune_joint(self, reps: int = 3, slack: float = 1.6):
+        """Second tuning pass of a plan with concurrent sub-batch chains.  Each chain has picked its tiles by timing its
+        launches ALONE on the chip; in the real forward the same layer of the other chain(s) runs beside it, and what
+        then counts is how well the two launches share a CU (LDS footprint, waves, issue slots), not the isolated time:
+        a 77 KiB-per-workgroup persistent kernel that is 16 % faster alone made the forward 2.6 % slower with two
+        workgroups per CU and 0.5 % faster with one (profiles/r02_band_persist.md).  So: per layer, every tile whose
+        isolated time is within `slack` of the best is timed again with ALL chains launching that layer at once (each on its own
+        stream), and the tile with the shortest joint time wins - the same for a fused pair against its two-launch form."""
+        subs = self.subs
+        lib_call = _lib.call
+
+        def joint_ms(launch):
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = None
+            for rnd in range(3):   # first round warms up
+                start.record(self.stream)
+                for sub in subs:
+                    sub.stream.wait_event(start)
+                    for _ in range(reps):
+                        launch(sub)
+                    j = torch.cuda.Event()
+                    j.record(sub.stream)
+                    self.stream.wait_event(j)
+                end.record(self.stream)
+                end.synchronize()
+                if rnd:
+                    t = start.elapsed_time(end)
+                    best = t if best is None else min(best, t)
+            return best
+
+        log = bool(os.environ.get("HAWQ_AUTOTUNE_LOG"))
+        with torch.cuda.stream(self.stream):
+            n_conv = len(subs[0]._conv_args)
+            if any(len(sub._conv_args) != n_conv or sub._conv_names != subs[0]._conv_names for sub in subs):
+                return
+            for k, name in enumerate(subs[0]._conv_names):
+                iso = {}
+                for sub in subs:   # a tile must be known to every chain; isolated time = the slowest chain's
+                    for t, v in sub._tile_times.get(name, {}).items():
+                        iso[t] = max(iso.get(t, 0.0), v)
+                iso = {t: v for t, v in iso.items() if all(t in sub._tile_times.get(name, {}) for sub in subs)}
+                if len(iso) < 2:
+                    continue
+                lim = slack * min(iso.values())
+                cand = sorted((t for t, v in iso.items() if v <= lim), key=iso.get)[:6]
+                res = {}
+                for t in cand:
+                    for sub in subs:
+                        sub._conv_args[k].tile = t
+                    res[t] = joint_ms(lambda sub: lib_call("hawq_conv2d", C.byref(sub._conv_args[k]), sub.stream.cuda_stream))
+                best = min(res, key=res.get)
+                if log:
+                    print(f"[joint tune] {name}: " + " ".join(f"{t}:{iso[t] / reps * 1e3:.1f}/{res[t] / reps * 1e3:.1f}" for t in cand)
+                          + f" (us alone / all chains) -> {best}", file=sys.stderr)
+                for sub in subs:
+                    sub._conv_args[k].tile = best
+                    sub.tile_choice[name] = best
+            n_er = len(subs[0]._er_args)
+            if all(len(sub._er_args) == n_er and sub._er_names == subs[0]._er_names for sub in subs):
+                for k, name in enumerate(subs[0]._er_names):
+                    res = {}
+                    variants = set.intersection(*(set(sub._er_times.get(name, {})) for sub in subs))
+                    for v in sorted(variants):
+                        for sub in subs:
+                            sub._er_args[k].er.tile, sub._er_args[k].fused = v, True
+                        res[v] = joint_ms(lambda sub: sub._er_args[k]())
+                    for sub in subs:   # the two-launch form with each chain's own best tiles
+                        sub._er_args[k].fused = False
+                    res[0] = joint_ms(lambda sub: sub._er_args[k]())
+                    best = min(res, key=res.get)
+                    if log:
+                        print(f"[joint tune] {name}+next reduce: " + " ".join(f"{v}:{t / reps * 1e3:.1f}" for v, t in sorted(res.items()))
+                              + f" (us, all chains; 0 = two launches) -> {best}", file=sys.stderr)
+                    for sub in subs:
+                        pair = sub._er_args[k]
+                        pair.fused = best != 0
+                        if best:
+                            pair.er.tile = best
+                        sub.er_choice[name] = best
+        torch.cuda.synchronize(self.dev)
+        for sub in subs:
+            sub.flags.zero_()
 
     # ------------------------------------------------------------------ execution
     def _launch_all(self, u8: bool = False):

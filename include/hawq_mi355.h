@@ -121,7 +121,8 @@ typedef struct hawq_conv_args {
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
 int hawq_conv2d_num_tiles(void);
 /* The LAST hawq_conv2d_num_band_tiles() tile ids are the 3x3/stride-1/pad-1 "band" kernels (fast-contract
- * int8 REQUANT layers only; hawq_conv2d refuses them for any other layer).  All other ids take any layer. */
+ * layers only; hawq_conv2d refuses them for any other layer); the last two are the weight-stationary persistent
+ * kernel for Cin == Cout == 64 (int8 in and out, REQUANT, NHWC output) with one / two workgroups per CU.  All other ids take any layer. */
 int hawq_conv2d_num_band_tiles(void);
 /* 1-based id of the preferred band tile that takes this layer as described (geometry, widths, epilogue,
  * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */

