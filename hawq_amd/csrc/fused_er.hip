@@ -36,6 +36,7 @@ struct ERP {
     int y_lo, y_hi;                    // clamp of the reduce conv's QuantAct (ReLU folded into y_lo)
     int y_planar;
     int32_t *flags;
+    int dbg;             // HAWQ_DBG ablations (timing experiments only): 256 = no residual stores, 512 = no residual loads
     long long *dbgbuf;   // HAWQ_DBG=128: per-phase cycle sums of wave 0 of workgroup 8 (timing experiments only)
 };
 
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 const int base = (i * F::NI + pw) * 64, idx = base + lane;
                 const int row = idx >> 3, jj = idx & 7;
                 const int grow = (m0 + row < p.M) ? m0 + row : m0;
-                dma16((const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
+                dma16((p.dbg & 512) ? zero : (const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
             }
         }
     };
@@ -223,9 +224,13 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
         // and waited for (the only younger memory operations of a compute wave are none; its stores are older)
         v4i rin[2];
         if constexpr (!F::RESDMA && !F::DUAL) {
+            if (p.dbg & 512) {
+                rin[0] = rin[1] = v4i{0, 0, 0, 0};
+            } else {
             const char *rp = (const char *)p.res_in + ((size_t)res_row * p.C3 + j * 64 + lch) * 2;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rin[0]) : "v"(rp) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rin[1]) : "v"(rp) : "memory");
+            }
         }
         if constexpr (F::NP == 0)   // after the residual loads: the counted wait in front of the epilogue leaves this group in flight
             if (j + 1 < nslices) {
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
 #pragma unroll
             for (int i = 0; i < F::BM * 8 / F::NTC; ++i) {
                 const int idx = t + F::NTC * i, row = idx >> 3, jj = idx & 7;
-                if (m0 + row < p.M)
+                if (m0 + row < p.M && !(p.dbg & 256))
                     *reinterpret_cast<v4i *>((char *)p.res_out + ((size_t)(m0 + row) * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4)) =
                         *reinterpret_cast<const v4i *>(src + idx * 16);
             }
@@ -465,6 +470,7 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     static long long *dbg_dev = nullptr;
     if ((dbg_env & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
     p.dbgbuf = (dbg_env & 128) ? dbg_dev : nullptr;
+    p.dbg = dbg_env;
     const ERInfo &ei = kER[v];
     static const bool attrs = [] {
         bool good = true;

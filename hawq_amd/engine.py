@@ -750,7 +750,7 @@ class IntegerEngine:
         torch.cuda.synchronize(self.dev)
         self.flags.zero_()  # tuning launches ran on whatever the buffers held; only real forwards may raise the flag
 
-    def _autotune_joint(self, reps: int = 3, slack: float = 1.6):
+    def _autotune_joint(self, reps: int = 4, slack: float = 1.6, top: int = 6):
         """Second tuning pass of a plan with concurrent sub-batch chains.  Each chain has picked its tiles by timing its
         launches ALONE on the chip; in the real forward the same layer of the other chain(s) runs beside it, and what
         then counts is how well the two launches share a CU (LDS footprint, waves, issue slots), not the isolated time:
@@ -760,11 +760,12 @@ class IntegerEngine:
         stream), and the tile with the shortest joint time wins - the same for a fused pair against its two-launch form."""
         subs = self.subs
         lib_call = _lib.call
+        slack, top = float(os.environ.get("HAWQ_JOINT_SLACK", slack)), int(os.environ.get("HAWQ_JOINT_TOP", top))
 
         def joint_ms(launch):
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             best = None
-            for rnd in range(3):   # first round warms up
+            for rnd in range(4):   # first round warms up, then the minimum of three
                 start.record(self.stream)
                 for sub in subs:
                     sub.stream.wait_event(start)
@@ -794,7 +795,7 @@ class IntegerEngine:
                 if len(iso) < 2:
                     continue
                 lim = slack * min(iso.values())
-                cand = sorted((t for t, v in iso.items() if v <= lim), key=iso.get)[:6]
+                cand = sorted((t for t, v in iso.items() if v <= lim), key=iso.get)[:top]
                 res = {}
                 for t in cand:
                     for sub in subs:
