@@ -139,7 +139,7 @@ class IntegerEngine:
             raise RuntimeError("IntegerEngine: move the model to the MI355X first (no CPU path)")
         self.res_bits = residual_bits
         self.from_buffers = from_buffers
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not os.environ.get("HAWQ_NO_GRAPH")  # (HAWQ_NO_GRAPH: direct launches, for experiments)
         self.keep_acc = keep_accumulators
         self.fast = fast  # False forces the exact general kernels everywhere (reference for tests)
         self.autotune = autotune  # pick each conv launch's tile configuration by timing it once per batch shape
