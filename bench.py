@@ -302,6 +302,7 @@ def main():
                        "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
                        # candidate expand->reduce pairs: variant id of the fused launch, 0 = two separate launches were faster
                        "fused_expand_reduce_launches": sum(1 for v in eng.er_choice.values() if v), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
+                       "fused_pairs": [n for n, v in eng.er_choice.items() if v],
                        "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(eng, "er_split_tiles", {}).values()),
                        "concurrent_sub_batches": eng.chains},
             # all logits of this rank's images against the CPU oracle's golden logits of the same workload
@@ -322,7 +323,8 @@ def main():
                          "gpu_ms_per_launch": round(gpu_ms, 4), "algorithmic_bytes_per_launch": alg,
                          # what the fused plan must move at minimum (hawq_amd/roofline.py:fused_plan_table); "traffic"
                          # is its measured counterpart
-                         "fused_plan_bytes_per_launch": roofline.fused_plan_bytes(args.arch, args.scheme, local_batch),
+                         "fused_plan_bytes_per_launch": roofline.fused_plan_bytes(args.arch, args.scheme, local_batch,
+                                                                                  [n for n, v in eng.er_choice.items() if v]),
                          "mfma_frac": round(mfma_frac, 4)},
         }
         if (not args.no_extra or args.per_op) and world == 1:

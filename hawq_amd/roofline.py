@@ -145,6 +145,13 @@ def fused_plan_table(arch: str, scheme: str, size: int = 224):
     return rows
 
 
-def fused_plan_bytes(arch: str, scheme: str, batch: int) -> int:
+def fused_plan_bytes(arch: str, scheme: str, batch: int, fused_pairs=()) -> int:
+    """Bytes per launch of the plan.  `fused_pairs`: names of the expand convs ("stage1.unit2.quant_convbn3") whose launch also
+    runs the next unit's reduce conv (hawq_conv_expand_reduce): that unit's 8-bit block input is then neither written nor read."""
     rows = fused_plan_table(arch, scheme)
-    return batch * sum(r["read"] + r["write"] for r in rows) + sum(r["weight_bytes"] for r in rows)
+    total = batch * sum(r["read"] + r["write"] for r in rows) + sum(r["weight_bytes"] for r in rows)
+    names = [r["name"] for r in rows]
+    for pair in fused_pairs:
+        i = next(k for k, n in enumerate(names) if n.split("+")[0] == pair)
+        total -= 2 * batch * rows[i + 1]["read"]   # the row after an expand conv is the next unit's quant_convbn1: its input is that tensor
+    return total

@@ -32,6 +32,7 @@ done
 rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -o r -- python $R/bench.py --no-cpu-baseline --no-extra --steps 6 --warmup 1 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) 8 > $O/${tag}_pmc_MFMA.md
 python $R/tools/pmc_total.py $(find /tmp/pm -name "*.db" | head -1) > $O/${tag}_pmc_MFMA_totals.txt
+python $R/tools/mfma_util.py $O/${tag}_pmc_MFMA.md > $O/${tag}_mfma_utilisation.md
 python - <<PY
 import json, re
 tot = {}
@@ -44,7 +45,7 @@ write_kb = (tot[("WRITE_SIZE", 12)] - tot[("WRITE_SIZE", 2)]) / 10
 b = json.loads(open("$O/${tag}_bench.json").readline())
 out = {b["config"]["workload"]: {
     "bytes_per_launch": round((2 * fetch_kb + write_kb) * 1000.0), "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
-    "git_head": "${GRAFT_HEAD:-unknown}", "tag": "$tag",
+    "git_head": "${GRAFT_HEAD:-unknown}", "tag": "$tag", "fused_pairs": b["config"].get("fused_pairs", []),
     "config": f"{b['config']['concurrent_sub_batches']} concurrent sub-batches, tiles {b['config']['autotuned_tiles']}, fused variants {b['config']['fused_variants']} replayed",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only), counter summed over ALL dispatches of bench.py --no-cpu-baseline --no-extra --warmup 1 at --steps 12 minus the same at --steps 2, divided by 10 forwards (tools/profile_round.sh, tools/pmc_total.py); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16 B/lane streams); KB = 1000 B"}}
 json.dump(out, open("$O/${tag}_traffic.json", "w"), indent=1)
