@@ -394,13 +394,15 @@ using E128D = ERCfg<128, 2, 0, true, 3>;    //          residual prefetched into
 using E128P = ERCfg<128, 2, 4, true, 4>;    //          4 + 4 waves (producers own the LDS-DMA), two workgroups per CU
 using E256 = ERCfg<256, 4, 0, false, 2>;    // stage 3: 128 pixels, 8 waves, 106 KiB, one workgroup per CU
 using E256P = ERCfg<256, 4, 4, true, 3>;    //          8 + 4 waves, residual prefetched into LDS, 122 KiB
+using E256S = ERCfg<256, 2, 0, false, 2>;   //          64 pixels, 4 waves, residual through registers, 78 KiB: two workgroups per CU, twice the workgroups
+using E256SP = ERCfg<256, 2, 4, true, 2>;    //          64 pixels, 4 + 4 waves, 86 KiB
 using E64D = ERCfg<64, 2, 0, false, 4, true>;   // stage 1, first unit: identity conv as a second GEMM1, 46 KiB
-constexpr int NUM_ER = 8;
+constexpr int NUM_ER = 10;
 
 typedef void (*ERFn)(const ERP);
 struct ERInfo { ERFn fn[2]; int c, bm, nt, lds; bool dual; };
 #define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::DUAL}
-const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P), ER_ENTRY(E64D)};
+const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P), ER_ENTRY(E256S), ER_ENTRY(E256SP), ER_ENTRY(E64D)};
 
 bool conv_is_1x1_int8_fast(const hawq_conv_args &a, bool dual_ok = false) {
     return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 &&

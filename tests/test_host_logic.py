@@ -148,7 +148,7 @@ def test_fused_plan_byte_model():
     pairs = rec.get("fused_pairs", [])
     model = R.fused_plan_bytes("resnet50", "uniform8", 128, pairs)
     assert model == R.fused_plan_bytes("resnet50", "uniform8", 128) - sum(
-        2 * 128 * {"1": 56 * 56 * 64, "2": 28 * 28 * 128, "3": 14 * 14 * 256}[p[len("stage")]] for p in pairs)
+        2 * 128 * {"1": 56 * 56 * 256, "2": 28 * 28 * 512, "3": 14 * 14 * 1024}[p[len("stage")]] for p in pairs)
     # (the counters see L2 misses: a residual slice that is still in L2 when its reader runs makes them read a little LESS than the model)
     assert 0.95 * model <= measured <= 1.25 * model, (model, measured)
 
