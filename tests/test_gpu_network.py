@@ -1,5 +1,7 @@
 """Whole-network GPU parity: hawq_amd (HIP) vs the live reference's golden fixtures and vs
 the CPU oracle.  Bit-exact on int32 accumulators, frozen ranges, logits and top-1."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -188,7 +190,18 @@ def test_concurrent_sub_batches_are_bit_identical():
             assert eng.chains in (1, 2, 3) and set(eng.chain_timing_ms) == {1, 2, 3}
         else:
             assert eng.chains == chains and len(eng.subs) == chains
+            # the joint tuning pass leaves every chain with the same tile / fused-variant choice per layer
+            for sub in eng.subs[1:]:
+                assert [a.tile for a in sub._conv_args] == [a.tile for a in eng.subs[0]._conv_args]
+                assert [(p.fused, p.er.tile if p.fused else (p.expand.tile, p.reduce.tile)) for p in sub._er_args] == \
+                       [(p.fused, p.er.tile if p.fused else (p.expand.tile, p.reduce.tile)) for p in eng.subs[0]._er_args] or \
+                       all(p.fused == q.fused for p, q in zip(sub._er_args, eng.subs[0]._er_args))
         assert not eng.overflowed()
+    os.environ["HAWQ_JOINT_TUNE"] = "0"   # isolated timing only: another plan, the same logits
+    try:
+        assert torch.equal(IntegerEngine(model, chains=2)(x), ref)
+    finally:
+        del os.environ["HAWQ_JOINT_TUNE"]
 
 
 def test_model_call_uses_fused_engine_and_cpu_raises():
