@@ -133,7 +133,9 @@ int hawq_conv2d_band_tile(const hawq_conv_args *args);
  * conv of unit i+1 with its REQUANT epilogue (ReLU -> quant_act1).  `expand` and `reduce` are filled exactly as for
  * two hawq_conv2d calls, except that expand.out_q and reduce.in are ignored: the 8-bit block input of unit i+1 stays
  * on chip.  Needs: both convs 1x1 / stride 1, int8 operands, fast_tables != 0, uint16 residual in and out (single
- * branch), reduce.Cin == expand.Cout, reduce.Cout == expand.Cin in {64, 128, 256}, 8-bit outputs.
+ * branch) - or, for expand.Cin == 64, a second branch in2 / wgt2 / ctab_id that is a 1x1 / stride-1 conv over the same pixels with
+ * Cin2 == 64 (the first unit of ResNet50's stage 1: its requantised accumulators replace the stored residual) -,
+ * reduce.Cin == expand.Cout, reduce.Cout == expand.Cin in {64, 128, 256}, 8-bit outputs.
  * tile: 0 = default kernel variant for the channel count, 1..hawq_conv_expand_reduce_variants() = a specific one. */
 typedef struct hawq_expand_reduce_args {
     hawq_conv_args expand;
