@@ -377,17 +377,53 @@ class IntegerEngine:
         """Allocate activation buffers for batch N and record the launch list (choosing the chain count first
         when it was left open)."""
         if x_view is None and getattr(self, "chains_req", 1) == 0 and self.use_graph and self.autotune:
-            timing = {}
+            timing, plans = {}, {}
             # small batches (what one GPU sees when 128 images are sharded over 4 / 8 ranks) launch fewer workgroups
             # than the chip has CUs in most layers: two concurrent half-batches can still pay, three never did
             for c in ((1, 2, 3) if N >= 48 else ((1, 2) if N >= 8 else (1,))):
                 self.chains = c
                 self._build_chains(N, H, W)
                 timing[c] = self._time_graph() if N >= 8 else 0.0
+                plans[c] = self._plan_snapshot()
                 self._drop_graph()
             self.chains = min(timing, key=timing.get)
             self.chain_timing_ms = timing
+            self._build_chains(N, H, W, x_view, logits_view)
+            # the rebuild tuned again (timing noise makes two tuning runs differ in a few layers): keep whichever of the two
+            # plans for this chain count replays faster
+            if N >= 8 and plans.get(self.chains) is not None:
+                fresh = self._plan_snapshot()
+                t_fresh = self._time_graph(16)
+                self._plan_apply(plans[self.chains])
+                t_kept = self._time_graph(16)
+                if t_fresh < t_kept:
+                    self._plan_apply(fresh)
+                self.plan_trials_ms = (round(t_kept, 4), round(t_fresh, 4))
+            return
         self._build_chains(N, H, W, x_view, logits_view)
+
+    def _plan_snapshot(self):
+        """Tile / fused-variant choice of every launch of the current plan (one entry per chain)."""
+        return [dict(tiles=[a.tile for a in e._conv_args],
+                     pairs=[(p.fused, p.er.tile, p.expand.tile, p.reduce.tile) for p in e._er_args],
+                     tile_choice=dict(e.tile_choice), er_choice=dict(e.er_choice), er_split=dict(getattr(e, "er_split_tiles", {})))
+                for e in (self.subs or [self])]
+
+    def _plan_apply(self, plan):
+        engines = self.subs or [self]
+        if len(plan) != len(engines) or any(len(pl["tiles"]) != len(e._conv_args) or len(pl["pairs"]) != len(e._er_args)
+                                            for pl, e in zip(plan, engines)):
+            return
+        for pl, e in zip(plan, engines):
+            for a, t in zip(e._conv_args, pl["tiles"]):
+                a.tile = t
+            for p, (fused, vt, te, tr) in zip(e._er_args, pl["pairs"]):
+                p.fused, p.er.tile, p.expand.tile, p.reduce.tile = fused, vt, te, tr
+            e.tile_choice.clear(), e.tile_choice.update(pl["tile_choice"])
+            e.er_choice.clear(), e.er_choice.update(pl["er_choice"])
+            if hasattr(e, "er_split_tiles"):
+                e.er_split_tiles.clear(), e.er_split_tiles.update(pl["er_split"])
+        self._drop_graph()
 
     def _drop_graph(self):
         for attr in ("_graph", "_graph_u8"):
