@@ -303,7 +303,7 @@ def main():
                        # candidate expand->reduce pairs: variant id of the fused launch, 0 = two separate launches were faster
                        "fused_expand_reduce_launches": sum(1 for v in eng.er_choice.values() if v), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
                        "fused_pairs": [n for n, v in eng.er_choice.items() if v],
-                       # ms per forward of the two independently tuned plans the engine chose between (kept, re-tuned)
+                       # ms per forward of the independently tuned plans the engine chose between
                        "plan_trials_ms": getattr(eng, "plan_trials_ms", None),
                        "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(eng, "er_split_tiles", {}).values()),
                        "concurrent_sub_batches": eng.chains},
