@@ -289,6 +289,7 @@ def main():
         except OSError:
             pass
         mfma_frac = 2 * macs / (gpu_ms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12)
+        fused_pairs = [n for n, v in eng.er_choice.items() if v and not n.endswith("@solo")]
         hbm_traffic_frac = traffic / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS if traffic else None
         out = {
             "metric": "images/sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world,
@@ -301,8 +302,10 @@ def main():
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "exact_tie_requant_launches": eng.n_tie,
                        "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
                        # candidate expand->reduce pairs: variant id of the fused launch, 0 = two separate launches were faster
-                       "fused_expand_reduce_launches": sum(1 for v in eng.er_choice.values() if v), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
-                       "fused_pairs": [n for n, v in eng.er_choice.items() if v],
+                       "fused_expand_reduce_launches": len(fused_pairs), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
+                       "fused_pairs": fused_pairs,
+                       # expand convs without a fusable successor that run the wave-private kernel (fused_wp.hip) alone
+                       "wave_private_solo_launches": [n[:-5] for n, v in eng.er_choice.items() if v and n.endswith("@solo")],
                        # ms per forward of the independently tuned plans the engine chose between
                        "plan_trials_ms": getattr(eng, "plan_trials_ms", None),
                        "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(eng, "er_split_tiles", {}).values()),
@@ -326,7 +329,7 @@ def main():
                          # what the fused plan must move at minimum (hawq_amd/roofline.py:fused_plan_table); "traffic"
                          # is its measured counterpart
                          "fused_plan_bytes_per_launch": roofline.fused_plan_bytes(args.arch, args.scheme, local_batch,
-                                                                                  [n for n, v in eng.er_choice.items() if v]),
+                                                                                  fused_pairs),
                          "mfma_frac": round(mfma_frac, 4)},
         }
         if (not args.no_extra or args.per_op) and world == 1:

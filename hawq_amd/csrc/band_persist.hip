@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
     }
     const int Wo = p.Wo, Wb = Wo + 2;
     const char *zero = reinterpret_cast<const char *>(g_bp_zero16);
-    const bool prof = p.dbgbuf != nullptr;
+    const bool prof = HAWQ_DBG_BIT(~0, 128) && p.dbgbuf != nullptr;
     long long ph[5] = {0, 0, 0, 0, 0};
     long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define BP_STAMP(K)                                                    \
@@ -259,8 +259,8 @@ int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs
     p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
     p.ntiles = (p.M + BM - 1) / BM;
     static long long *dbg_dev = nullptr;
-    if ((dbg & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 8 * sizeof(long long));
-    p.dbgbuf = (dbg & 128) ? dbg_dev : nullptr;
+    if (HAWQ_DBG_BIT(dbg, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 8 * sizeof(long long));
+    p.dbgbuf = HAWQ_DBG_BIT(dbg, 128) ? dbg_dev : nullptr;
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;

@@ -28,6 +28,20 @@ void hawq_set_error(const char *fmt, ...);
         }                             \
     } while (0)
 
+// ---- timing ablations / cycle stamps (probe builds only) ------------------------------------
+// HAWQ_DBG=<bits> makes kernels skip loads / MFMAs / epilogues / stores (results wrong on purpose) or stamp
+// s_memtime phases.  That code exists only in a library built with -DHAWQ_ABLATE (`make ABLATE=1` ->
+// lib/libhawq_mi355_ablate.so, selected with HAWQ_LIB=...); the shipped library never reads the variable and
+// the bit tests below fold to constants.
+#ifdef HAWQ_ABLATE
+#include <stdlib.h>
+#define HAWQ_DBG_ENV() (getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0)
+#define HAWQ_DBG_BIT(v, bits) ((v) & (bits))
+#else
+#define HAWQ_DBG_ENV() 0
+#define HAWQ_DBG_BIT(v, bits) 0
+#endif
+
 // ---- dyadic requantisation ---------------------------------------------------------------
 // Table entry = (m, ek) with ek = e | k << 8:   q = round_half_even(((v << k) * m) / 2^e),
 // 0 <= m < 2^31, 1 <= e <= 62, k >= 0 small (host guarantees |v << k| < 2^31).  The pre-shift k

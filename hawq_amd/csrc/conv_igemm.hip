@@ -424,8 +424,8 @@ __device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&
             }
         }
         __builtin_amdgcn_s_barrier();
-        if (jissue < nk && !(p.dbg & 1)) issue();
-        if (!(p.dbg & 2)) compute(a, cstage);
+        if (jissue < nk && !HAWQ_DBG_BIT(p.dbg, 1)) issue();
+        if (!HAWQ_DBG_BIT(p.dbg, 2)) compute(a, cstage);
         if (++cstage == NS) cstage = 0;
     };
     for (int k = 0; k < ns1; ++k) step(acc, k);
@@ -715,8 +715,8 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
         }
         }  // qp
     }
-    if (RES && (oor >> 16) != 0 && p.res_out && !p.dbg) atomicOr(p.flags, 1);
-    if (p.dbg & 8) return;  // rows beyond M never reach memory but may flag: harmless
+    if (RES && (oor >> 16) != 0 && p.res_out && !HAWQ_DBG_BIT(p.dbg, ~0)) atomicOr(p.flags, 1);
+    if (HAWQ_DBG_BIT(p.dbg, 8)) return;  // rows beyond M never reach memory but may flag: harmless
     __syncthreads();
     const int t = threadIdx.x;
     if constexpr (RES) {
@@ -783,7 +783,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 template <class C, int EPI, bool DUAL, int BITS, int BITS2, bool TIE = false>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool prof = (p.dbg & 128) && p.dbgbuf;  // HAWQ_DBG=128: cycle stamps of one wave (tools/convprobe.py)
+    const bool prof = HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf;  // HAWQ_DBG=128: cycle stamps of one wave (tools/convprobe.py)
     const long long t_entry = prof ? (long long)__builtin_readcyclecounter() : 0;
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give
     // each XCD a contiguous run of pixel tiles that share the same weight tile in its L2.
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
             run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2,
                                   0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
     }
-    if (p.dbg & 4) return;
+    if (HAWQ_DBG_BIT(p.dbg, 4)) return;
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
     const int kgrp = (threadIdx.x >> 6) / C::NWG;
     if constexpr (C::KG > 1) {
@@ -956,7 +956,7 @@ struct BandCfg {
 template <class C, bool NIB = false, bool TIE = false, int EPI = HAWQ_EPI_REQUANT>
 __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const ConvP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool prof = (p.dbg & 128) && p.dbgbuf;
+    const bool prof = HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf;
     const long long t_entry = prof ? (long long)__builtin_readcyclecounter() : 0;
     const int tiles_c = p.Cout / C::BN;
     const int nwg = ((p.M + C::BM - 1) / C::BM) * tiles_c;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < nsteps; ++s) {
-            if (!(p.dbg & 1)) issue_step(s, cc, kh);
+            if (!HAWQ_DBG_BIT(p.dbg, 1)) issue_step(s, cc, kh);
             wait_step(s, cc, kh);
             __builtin_amdgcn_s_barrier();
             if (++kh == 3) kh = 0, ++cc;
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         // fragments of the next batch are requested from LDS before the MFMAs of the current one are issued.
         v4i wf[2][C::CT], af[2][C::PT];
 #define BAND_FETCH(B, BUF)                                                                                        \
-    if (!(p.dbg & 4)) {                                                                                           \
+    if (!HAWQ_DBG_BIT(p.dbg, 4)) {                                                                                           \
         _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                                         \
             wf[BUF][c] = lds_read16<((B) >> 1) * C::WTAP>(wp[c][(B) & 1]);                                        \
         _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                                         \
@@ -1174,11 +1174,11 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv3x3_band_kernel(const Conv
         BAND_FETCH(0, 0)
         for (int s = 0; s < nsteps; ++s) {
             BAND_BATCH(0)
-            if (C::NPROD == 0 && early && !(p.dbg & 1)) issue_step(s, cc, kh);
+            if (C::NPROD == 0 && early && !HAWQ_DBG_BIT(p.dbg, 1)) issue_step(s, cc, kh);
             BAND_BATCH(1)
             BAND_BATCH(2)
             BAND_BATCH(3)
-            if (C::NPROD == 0 && !early && !(p.dbg & 1)) issue_step(s, cc, kh);
+            if (C::NPROD == 0 && !early && !HAWQ_DBG_BIT(p.dbg, 1)) issue_step(s, cc, kh);
             BAND_BATCH(4)
             if (++kh == 3) kh = 0, ++cc;
             if (s + 1 < nsteps) {  // first fragments of the next step (its operands are visible since the previous barrier)
@@ -1410,12 +1410,12 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
     p.flags = a->flags;
     p.ctab = a->ctab, p.ctab_id = a->ctab_id;
-    static const int dbg_env = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
+    static const int dbg_env = HAWQ_DBG_ENV();
     p.dbg = a->fast_tables ? dbg_env : 0;  // ablations only touch the fused-plan launches
     p.dbgbuf = nullptr;
     static long long *dbg_dev = nullptr;
-    if ((p.dbg & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
-    if (p.dbg & 128) p.dbgbuf = dbg_dev;
+    if (HAWQ_DBG_BIT(p.dbg, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
+    if (HAWQ_DBG_BIT(p.dbg, 128)) p.dbgbuf = dbg_dev;
     const bool fast = a->fast_tables != 0;
     p.k0 = (a->fast_tables & 4) ? 2 : ((a->fast_tables & 2) ? 1 : 0);
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
@@ -1504,7 +1504,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         const int grid_b = ((p.M + bi.bm - 1) / bi.bm) * (p.Cout / bi.bn);
         hipLaunchKernelGGL(bi.fn[nib ? 1 : 0][p.k0 == 2 ? 1 : 0][res ? 1 : 0], dim3(grid_b), dim3(bi.nt), bi.lds, (hipStream_t)stream, p);
         HAWQ_CHECK_HIP(hipGetLastError());
-        if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
+        if (HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
             long long hbuf[4];
             (void)hipStreamSynchronize((hipStream_t)stream);
             (void)hipMemcpy(hbuf, p.dbgbuf, sizeof(hbuf), hipMemcpyDeviceToHost);
@@ -1575,7 +1575,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     HAWQ_REQUIRE(attrs_ok, "hawq_conv2d: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     hipLaunchKernelGGL(fn, dim3(grid), dim3(ti.nt), lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
-    if ((p.dbg & 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
+    if (HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf) {  // experiment hook: per-phase cycles of one wave (synchronises!)
         long long hbuf[4];
         (void)hipStreamSynchronize((hipStream_t)stream);
         (void)hipMemcpy(hbuf, p.dbgbuf, sizeof(hbuf), hipMemcpyDeviceToHost);

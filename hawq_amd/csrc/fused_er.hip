@@ -109,7 +109,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
     const int nslices = p.C3 >> 6;
     char *x2t = smem + F::OFF_X2, *ring = smem + F::OFF_RING, *qt = smem + F::OFF_Q, *rest = smem + F::OFF_RES;
     char *ct3 = smem + F::OFF_CT3;
-    const bool prof = p.dbgbuf != nullptr;
+    const bool prof = HAWQ_DBG_BIT(~0, 128) && p.dbgbuf != nullptr;
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define ER_STAMP(K)                                                    \
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 const int base = (i * F::NI + pw) * 64, idx = base + lane;
                 const int row = idx >> 3, jj = idx & 7;
                 const int grow = (m0 + row < p.M) ? m0 + row : m0;
-                dma16((p.dbg & 512) ? zero : (const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
+                dma16(HAWQ_DBG_BIT(p.dbg, 512) ? zero : (const char *)p.res_in + ((size_t)grow * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4), dst + base * 16);
             }
         }
     };
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
         // and waited for (the only younger memory operations of a compute wave are none; its stores are older)
         v4i rin[2];
         if constexpr (!F::RESDMA && !F::DUAL) {
-            if (p.dbg & 512) {
+            if (HAWQ_DBG_BIT(p.dbg, 512)) {
                 rin[0] = rin[1] = v4i{0, 0, 0, 0};
             } else {
             const char *rp = (const char *)p.res_in + ((size_t)res_row * p.C3 + j * 64 + lch) * 2;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
 #pragma unroll
             for (int i = 0; i < F::BM * 8 / F::NTC; ++i) {
                 const int idx = t + F::NTC * i, row = idx >> 3, jj = idx & 7;
-                if (m0 + row < p.M && !(p.dbg & 256))
+                if (m0 + row < p.M && !HAWQ_DBG_BIT(p.dbg, 256))
                     *reinterpret_cast<v4i *>((char *)p.res_out + ((size_t)(m0 + row) * p.C3 + j * 64) * 2 + ((jj ^ (row & 7)) << 4)) =
                         *reinterpret_cast<const v4i *>(src + idx * 16);
             }
@@ -436,8 +436,13 @@ int er_variant(const hawq_expand_reduce_args *a) {
 
 }  // namespace
 
-extern "C" int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *a) {
-    if (!a) return 0;
+// wave-private variants (fused_wp.hip): numbered after the variants of this file; they also take reduce.wgt == NULL
+int wp_num_variants(const hawq_expand_reduce_args *a);
+int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream);
+
+namespace {
+int er_count(const hawq_expand_reduce_args *a) {   // variants of THIS file that take the pair
+    if (!a->reduce.wgt) return 0;
     hawq_expand_reduce_args q = *a;
     q.tile = 0;
     if (er_variant(&q) < 0) return 0;
@@ -445,9 +450,17 @@ extern "C" int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *a
     for (int i = 0; i < NUM_ER; ++i) n += kER[i].c == a->expand.Cin && kER[i].dual == (a->expand.in2 != nullptr);
     return n;
 }
+}  // namespace
+
+extern "C" int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *a) {
+    if (!a) return 0;
+    return er_count(a) + wp_num_variants(a);
+}
 
 extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *stream) {
     HAWQ_REQUIRE(a != nullptr, "hawq_conv_expand_reduce: null args");
+    const int n_er = er_count(a);
+    if (a->tile > n_er || (a->tile == 0 && n_er == 0)) return wp_launch(a, a->tile == 0 ? 1 : a->tile - n_er, stream);
     const int v = er_variant(a);
     HAWQ_REQUIRE(v >= 0, "hawq_conv_expand_reduce: this pair of layers cannot be fused (need 1x1/stride-1 int8 fast-contract convs, "
                          "uint16 residual in and out - or a same-shape 1x1 identity branch with Cin 64 -, Cin in {64,128,256}, reduce.Cin == expand.Cout, reduce.Cout == expand.Cin; tile %d)", a->tile);
@@ -468,10 +481,10 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     p.y_lo = r.relu && r.q_lo < 0 ? 0 : r.q_lo, p.y_hi = r.q_hi;
     p.y_planar = r.out_planar;
     p.flags = e.flags;
-    static const int dbg_env = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
+    static const int dbg_env = HAWQ_DBG_ENV();
     static long long *dbg_dev = nullptr;
-    if ((dbg_env & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
-    p.dbgbuf = (dbg_env & 128) ? dbg_dev : nullptr;
+    if (HAWQ_DBG_BIT(dbg_env, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(long long));
+    p.dbgbuf = HAWQ_DBG_BIT(dbg_env, 128) ? dbg_dev : nullptr;
     p.dbg = dbg_env;
     const ERInfo &ei = kER[v];
     static const bool attrs = [] {

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
             const int img = gg / (39 * (SF_PW / 4)), rem = gg - img * (39 * (SF_PW / 4));
             const int r = rem / (SF_PW / 4), c = (rem - r * (SF_PW / 4)) * 4;
             const int iy = 4 * py0 - 5 + r, ix = 4 * px0 - 5 + c, n = n0 + img;
-            const bool rowok = g < NG && n < N && (unsigned)iy < (unsigned)H && !(dbg & 16);
+            const bool rowok = g < NG && n < N && (unsigned)iy < (unsigned)H && !HAWQ_DBG_BIT(dbg, 16);
             gaddr[k] = img * SF_PATCH + (r * SF_PW + c) * 4;
             gmask[k] = 0;
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
         const int img = gg / (39 * (SF_PW / 4)), rem = gg - img * (39 * (SF_PW / 4));
         const int r = rem / (SF_PW / 4), c = (rem - r * (SF_PW / 4)) * 4;
         const int iy = 4 * py0 - 5 + r, ix = 4 * px0 - 5 + c, n = n0 + img;
-        const bool rowok = g < NG && n < N && (unsigned)iy < (unsigned)H && !(dbg & 16);
+        const bool rowok = g < NG && n < N && (unsigned)iy < (unsigned)H && !HAWQ_DBG_BIT(dbg, 16);
         gaddr[k] = img * SF_PATCH + (r * SF_PW + c) * 4;
         gmask[k] = 0;
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) best[r] = (int)0x80000000;
 #pragma unroll 1
-    for (int dy = 0; dy < ((dbg & 32) ? 1 : 3); ++dy) {  // not unrolled: keeps the 9 window tiles from living at once
+    for (int dy = 0; dy < (HAWQ_DBG_BIT(dbg, 32) ? 1 : 3); ++dy) {  // not unrolled: keeps the 9 window tiles from living at once
         const int cy = 2 * py + dy - 1;
 #pragma unroll 1
         for (int dx = 0; dx < 3; ++dx) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
         }
     }
     {
-        if (!pvalid || (dbg & 64)) continue;
+        if (!pvalid || HAWQ_DBG_BIT(dbg, 64)) continue;
         const int ch = c * 32 + h * 16;
         int r16[16], qa[16];
 #pragma unroll
@@ -627,7 +627,7 @@ int stem_fused_launch(const float *x, const uint8_t *xu8, const int8_t *lut, int
     const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;  // max-pool 3x3 / 2, pad 1
     const long long blocks = (long long)((Wp + 7) / 8) * ((Hp + 7) / 8) * ((N + 1) / 2);
     HAWQ_REQUIRE(blocks < (1ll << 31), "hawq_stem_fused: problem too large");
-    const int dbg = getenv("HAWQ_DBG") ? atoi(getenv("HAWQ_DBG")) : 0;
+    const int dbg = HAWQ_DBG_ENV();
     if (xu8)
         hipLaunchKernelGGL(stem_fused_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, xu8, lut, N, C, H,
                            W, inv_scale, in_lo, in_hi, wgt, bias, m, e, a_lo, a_hi, Hc, Wc, Hp, Wp, res_out, out_q, out_bits,

@@ -70,6 +70,8 @@ class _FusedPair:
     autotuner measured faster for this batch shape (results are identical)."""
 
     def __init__(self, er, expand, reduce, stream):
+        # reduce None: a "solo" entry - the expand conv alone, either through hawq_conv_expand_reduce (reduce.wgt == NULL:
+        # the wave-private kernel of fused_wp.hip) or through hawq_conv2d
         self.er, self.expand, self.reduce, self.sp = er, expand, reduce, stream
         self.fused = True
 
@@ -78,7 +80,8 @@ class _FusedPair:
             _lib.call("hawq_conv_expand_reduce", C.byref(self.er), self.sp)
         else:
             _lib.call("hawq_conv2d", C.byref(self.expand), self.sp)
-            _lib.call("hawq_conv2d", C.byref(self.reduce), self.sp)
+            if self.reduce is not None:
+                _lib.call("hawq_conv2d", C.byref(self.reduce), self.sp)
 
 
 class _Conv:
@@ -220,7 +223,7 @@ class IntegerEngine:
                                out_bits=self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")]),
                                rng=_act_range(act.activation_bit, act.quant_mode),
                                fast=tables_fit_fast(mm, ee, c.vbits), tie=not tables_are_fast(mm, ee, c.vbits),
-                               k0=_no_preshift(ee))
+                               k0=_no_preshift(ee), ck0=_no_preshift(ee))
                     if ent['fast']:
                         ent['ctab'] = _i32(packing.pack_ctab(c.b_host, mm, ee), dev)
                     s_x, bits_x, rng_x = s_n, ent['out_bits'], ent['rng']
@@ -231,7 +234,7 @@ class IntegerEngine:
             s_o = self._scale(ao)
             last = d['convs'][-1]
             mm, ee = requant_table(last['s_last'], last['conv'].s_w, s_o, vbits=last['conv'].vbits)
-            last.update(m=_i32(mm, dev), e=_i32(ee, dev), k0=_no_preshift(ee))
+            last.update(m=_i32(mm, dev), e=_i32(ee, dev), k0=_no_preshift(ee), ck0=_no_preshift(ee))
             fast = tables_fit_fast(mm, ee, last['conv'].vbits)
             tie = not tables_are_fast(mm, ee, last['conv'].vbits)
             if fast:
@@ -240,6 +243,7 @@ class IntegerEngine:
                 m1, e1 = requant_table(s_a, d['ident'].s_w, s_o, vbits=d['ident'].vbits)
                 d['m_id'], d['e_id'] = _i32(m1, dev), _i32(e1, dev)
                 last['k0'] = last['k0'] and _no_preshift(e1)
+                last['ck0'] = last['ck0'] and _no_preshift(e1)
                 if tables_fit_fast(m1, e1, d['ident'].vbits):
                     d['ctab_id'] = _i32(packing.pack_ctab(d['ident'].b_host, m1, e1), dev)
                     tie = tie or not tables_are_fast(m1, e1, d['ident'].vbits)
@@ -351,7 +355,7 @@ class IntegerEngine:
         r.flags = self.flags.data_ptr()
         r.epilogue, r.relu = _lib.EPI_REQUANT, 1
         r.out_bits, r.q_lo, r.q_hi = 8, ent['rng'][0], ent['rng'][1]
-        r.fast_tables = 5 if ent.get('tie', False) else 1
+        r.fast_tables = (5 if ent.get('tie', False) else 1) | (8 if ent.get('ck0', False) else 0)
         r.out_q = 1  # placeholder for the applicability query
         if _lib.load().hawq_conv_expand_reduce_variants(C.byref(er)) == 0:
             return None
@@ -369,6 +373,19 @@ class IntegerEngine:
         pair = _FusedPair(er, a, r1, self.stream.cuda_stream)
         keep += [out, er, q, r1, pair]
         return pair, out, 8, planar
+
+    def _try_solo(self, a, u, keep):
+        """Expand conv launch `a` (RESIDUAL epilogue, single branch, completely filled) as a candidate for the
+        wave-private kernel (hawq_conv_expand_reduce with reduce.wgt == NULL): a _FusedPair without a reduce conv, or None."""
+        if not a.fast_tables or a.in2 or os.environ.get("HAWQ_NO_SOLO"):
+            return None
+        er = _lib.ExpandReduceArgs()
+        C.memmove(C.byref(er.expand), C.byref(a), C.sizeof(a))
+        if _lib.load().hawq_conv_expand_reduce_variants(C.byref(er)) == 0:
+            return None
+        pair = _FusedPair(er, a, None, self.stream.cuda_stream)
+        keep += [er, pair]
+        return pair
 
     def _alloc(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.dev)
@@ -408,7 +425,7 @@ class IntegerEngine:
     def _plan_snapshot(self):
         """Tile / fused-variant choice of every launch of the current plan (one entry per chain)."""
         return [dict(tiles=[a.tile for a in e._conv_args],
-                     pairs=[(p.fused, p.er.tile, p.expand.tile, p.reduce.tile) for p in e._er_args],
+                     pairs=[(p.fused, p.er.tile, p.expand.tile, p.reduce.tile if p.reduce is not None else 0) for p in e._er_args],
                      tile_choice=dict(e.tile_choice), er_choice=dict(e.er_choice), er_split=dict(getattr(e, "er_split_tiles", {})))
                 for e in (self.subs or [self])]
 
@@ -421,7 +438,9 @@ class IntegerEngine:
             for a, t in zip(e._conv_args, pl["tiles"]):
                 a.tile = t
             for p, (fused, vt, te, tr) in zip(e._er_args, pl["pairs"]):
-                p.fused, p.er.tile, p.expand.tile, p.reduce.tile = fused, vt, te, tr
+                p.fused, p.er.tile, p.expand.tile = fused, vt, te
+                if p.reduce is not None:
+                    p.reduce.tile = tr
             e.tile_choice.clear(), e.tile_choice.update(pl["tile_choice"])
             e.er_choice.clear(), e.er_choice.update(pl["er_choice"])
             if hasattr(e, "er_split_tiles"):
@@ -554,6 +573,8 @@ class IntegerEngine:
                     a.fast_tables = 3  # no pre-shift anywhere: the shorter requant
                 self.n_tie += int(a.fast_tables == 5)
                 self.n_k0 += int(a.fast_tables == 3)
+                if a.fast_tables and ent.get('ck0', False):
+                    a.fast_tables |= 8  # every per-channel pre-shift of this launch's ctab (and ctab_id) is zero
                 if a.fast_tables:
                     a.ctab = ent['ctab'].data_ptr()
                     if ci == len(u['convs']) - 1 and u['resize']:
@@ -611,6 +632,13 @@ class IntegerEngine:
                     self._er_names.append(tap_name)
                     ops.next_name = tap_name + "+" + nxt['name'] + ".quant_convbn1"
                     ops.append(pair)
+                    continue
+                solo = self._try_solo(a, u, keep) if (ci == len(u['convs']) - 1 and not self.keep_acc) else None
+                if solo is not None:
+                    self._er_args.append(solo)
+                    self._er_names.append(tap_name + "@solo")
+                    ops.next_name = tap_name
+                    ops.append(solo)
                     continue
                 self._conv_args.append(a)
                 self._conv_names.append(tap_name)
@@ -697,7 +725,10 @@ class IntegerEngine:
                 pair.er.tile = int(v)
                 pair.fused = pair.er.tile != 0
                 if not pair.fused:
-                    pair.expand.tile, pair.reduce.tile = (int(x) for x in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
+                    te, tr = (int(x) for x in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
+                    pair.expand.tile = te
+                    if pair.reduce is not None:
+                        pair.reduce.tile = tr
                 self.er_choice[name] = pair.er.tile
             return
         with torch.cuda.stream(self.stream):
@@ -755,7 +786,10 @@ class IntegerEngine:
                     er.tile = int(fixed_er.split(".")[k])
                     pair.fused = er.tile != 0
                     if not pair.fused:
-                        pair.expand.tile, pair.reduce.tile = (int(v) for v in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
+                        te, tr = (int(v) for v in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
+                        pair.expand.tile = te
+                        if pair.reduce is not None:
+                            pair.reduce.tile = tr
                     self.er_choice[name] = er.tile
                     continue
                 nvar = _lib.load().hawq_conv_expand_reduce_variants(C.byref(er))
@@ -773,8 +807,10 @@ class IntegerEngine:
                 er.tile = min(times, key=times.get)
                 self._er_times[name] = dict(times)
                 te, ms_e = best_tile(pair.expand)
-                tr, ms_r = best_tile(pair.reduce)
-                pair.expand.tile, pair.reduce.tile = te, tr
+                tr, ms_r = best_tile(pair.reduce) if pair.reduce is not None else (0, 0.0)
+                pair.expand.tile = te
+                if pair.reduce is not None:
+                    pair.reduce.tile = tr
                 pair.fused = times[er.tile] <= ms_e + ms_r
                 if os.environ.get("HAWQ_AUTOTUNE_LOG"):
                     log = [f"{t}:{v / reps * 1e3:.1f}" for t, v in times.items()]

@@ -82,6 +82,7 @@ def _case(lib, orc, n, h, w, c, c3, seed, force_tie=False, dual=False):
     rd.m, rd.e, rd.ctab = keep['m1'].data_ptr(), keep['e1'].data_ptr(), keep['ctab1'].data_ptr()
     rd.out_q, rd.out_bits, rd.q_lo, rd.q_hi = keep['y'].data_ptr(), 8, -128, 127
     rd.fast_tables = 1 if fast else 5
+    keep['q_ref'], keep['k0'] = q, bool(((np.asarray(e3) >> 8) == 0).all() and ((np.asarray(e1) >> 8) == 0).all())
     return a, keep, o, y
 
 
@@ -93,15 +94,50 @@ def test_expand_reduce_matches_oracle(lib, orc, shape, tie):
     a, keep, o, y = _case(lib, orc, n, h, w, c, c3, zlib.crc32(repr(shape).encode()), force_tie=tie)
     nvar = lib.load().hawq_conv_expand_reduce_variants(C.byref(a))
     assert nvar >= 1
+    ft = a.expand.fast_tables
     for tile in range(0, nvar + 1):
-        for planar in (0, 1):
+        for planar, k0 in ((0, 0), (1, 0)) + (((0, 8),) if keep['k0'] else ()):   # bit 3: all per-channel pre-shifts are zero
             a.tile, a.reduce.out_planar = tile, planar
+            a.expand.fast_tables = a.reduce.fast_tables = ft | k0
             keep['res_out'].zero_(), keep['y'].zero_()
             lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
             got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
-            assert np.array_equal(got, o), (tile, planar)
+            assert np.array_equal(got, o), (tile, planar, k0)
             gy = from_planar(keep['y'], (n, h, w, c), 8) if planar else unpack_q(keep['y'], (n, h, w, c), 8)
-            assert np.array_equal(gy, y), (tile, planar)
+            assert np.array_equal(gy, y), (tile, planar, k0)
+            assert keep['flags'].item() == 0
+    a.expand.fast_tables = a.reduce.fast_tables = ft
+    a.tile = nvar + 1
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 14, 14, 64, 256), (3, 9, 7, 128, 512), (1, 14, 14, 256, 1024), (2, 7, 7, 512, 2048),
+                                   (1, 3, 5, 128, 256), (128, 7, 7, 512, 2048), (16, 28, 28, 128, 512)])
+@pytest.mark.parametrize("tie", [False, True])
+def test_expand_alone_wave_private(lib, orc, shape, tie):
+    """reduce.wgt == NULL: the expand conv alone on the wave-private kernel (fused_wp.hip; last unit of a stage, every
+    stage-4 unit): 16-bit residual out (optional) and the next unit's 8-bit block input written from registers; gridDim.y
+    splits the output channels in some variants."""
+    n, h, w, c, c3 = shape
+    if n * h * w * c3 > 3e6 and tie:
+        pytest.skip("full-size case once")
+    a, keep, o, y = _case(lib, orc, n, h, w, c, c3, zlib.crc32(repr(shape).encode()) + 7, force_tie=tie)
+    a.reduce = lib.ExpandReduceArgs().reduce   # zeroed: no reduce conv
+    qbuf = torch.zeros(o.size, dtype=torch.uint8, device='cuda')
+    a.expand.out_q = qbuf.data_ptr()
+    nvar = lib.load().hawq_conv_expand_reduce_variants(C.byref(a))
+    assert nvar >= 1
+    ft = a.expand.fast_tables
+    for tile in range(0, nvar + 1):
+        for with_res, k0 in ((True, 0), (False, 0)) + (((True, 8),) if keep['k0'] else ()):
+            a.tile = tile
+            a.expand.fast_tables = ft | k0
+            a.expand.res_out = keep['res_out'].data_ptr() if with_res else None
+            keep['res_out'].zero_(), qbuf.zero_()
+            lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+            got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+            assert np.array_equal(got, o if with_res else np.zeros_like(o)), (tile, with_res, k0)
+            assert np.array_equal(unpack_q(qbuf, (n, h, w, c3), 8), keep['q_ref']), (tile, with_res, k0)
             assert keep['flags'].item() == 0
     a.tile = nvar + 1
     assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0

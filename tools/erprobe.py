@@ -9,7 +9,7 @@ from hawq_amd.quant_utils import requant_table
 lib.load()
 rng = np.random.default_rng(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024)):
+for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (7, 512, 2048)):
     M = N * h * h
     x2 = torch.from_numpy(rng.integers(0, 128, (M, c)).astype(np.int8)).cuda()
     w3 = rng.integers(-127, 128, (c3, c, 1, 1)).astype(np.int64); b3 = rng.integers(-2000, 2000, c3).astype(np.int64)
@@ -34,6 +34,37 @@ for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024)):
     rd.N, rd.H, rd.W, rd.Cin, rd.Cout, rd.KH, rd.KW, rd.stride, rd.pad = N, h, h, c3, c, 1, 1, 1, 0
     rd.in_bits = rd.w_bits = 8; rd.epilogue, rd.relu, rd.ctab, rd.fast_tables = lib.EPI_REQUANT, 1, keep[3].data_ptr(), 1
     rd.out_q, rd.out_bits, rd.q_lo, rd.q_hi = keep[6].data_ptr(), 8, -128, 127
+    def timeit(fn, reps=20):
+        fn()
+        e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1_.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1_) / reps * 1e3
+    sp = torch.cuda.current_stream().cuda_stream
+    if not os.environ.get("HAWQ_DBG"):
+        # the same two layers as separate hawq_conv2d launches (best tile each), then the expand conv alone on the wave-private kernel
+        qbuf = torch.zeros(M * c3, dtype=torch.uint8, device='cuda')
+        ex.out_q = qbuf.data_ptr()
+        best = {}
+        for name, conv in (("expand", ex), ("reduce", rd)):
+            if name == "reduce":
+                rd.in_ = qbuf.data_ptr()
+            for tile in range(1, lib.load().hawq_conv2d_num_tiles() + 1):
+                conv.tile = tile
+                if lib.load().hawq_conv2d(C.byref(conv), sp) != 0:
+                    continue
+                us = timeit(lambda: lib.load().hawq_conv2d(C.byref(conv), sp), 10)
+                if name not in best or us < best[name][1]:
+                    best[name] = (tile, us)
+            conv.tile = 0
+        print(f"N={N} {h}x{h} C={c} C3={c3} separate launches: expand tile {best['expand'][0]} {best['expand'][1]:.1f} us + reduce tile {best['reduce'][0]} {best['reduce'][1]:.1f} us", flush=True)
+        solo = lib.ExpandReduceArgs()
+        C.memmove(C.byref(solo.expand), C.byref(ex), C.sizeof(ex))
+        for tile in range(1, lib.load().hawq_conv_expand_reduce_variants(C.byref(solo)) + 1):
+            solo.tile = tile
+            print(f"N={N} {h}x{h} C={c} C3={c3} expand alone, wave-private variant {tile}: {timeit(lambda: lib.call('hawq_conv_expand_reduce', C.byref(solo), sp)):.1f} us", flush=True)
     for tile in range(1, lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) + 1):
         a.tile = tile
         lib.call("hawq_conv_expand_reduce", C.byref(a), None)
