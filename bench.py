@@ -8,10 +8,14 @@ W8A8 at batch 128 per GPU; W4A4 / mixed / ResNet18 reported in ``extra``).
 A step = one frozen forward of one batch: fp32 images resident in HBM -> fp32 logits in HBM
 (one hipGraph launch of the fused integer plan).  With N > 1 the path shards by batch, no data-path
 collective, and each step ends with one RCCL all_gather of the logits (the reference's DataParallel
-gather, quant_train.py:358):
-  --scaling weak   (default) every rank processes its own batch of 128; value = N * 128 * K / t
-  --scaling strong ONE batch of 128 is sharded 128/N images per rank; value = 128 * K / t
-Prints ONE JSON line on rank 0.
+gather, quant_train.py:358) through ``hawq_amd.dist.gather_logits``.  ``--gpus N`` without a launcher
+(no WORLD_SIZE in the environment) starts the N ranks itself (``torch.distributed.run`` on 127.0.0.1).
+A multi-rank run measures BOTH decompositions and reports ``--scaling`` (default weak) as ``value``:
+  weak    every rank processes its own batch of 128; value = N * 128 * K / t
+  strong  ONE batch of 128 is sharded 128/N images per rank; value = 128 * K / t
+``n_gpus`` is the number of ranks the process group actually has.  Prints ONE JSON line on rank 0.
+``--dry-spawn`` runs the same launch / shard / gather / report path on CPU (gloo) with a stand-in forward:
+what the CPU test of the N > 1 plumbing uses (there is no CPU path for the network itself).
 """
 from __future__ import annotations
 
@@ -19,6 +23,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +32,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+COPY_CEILING_GBS = 6290.0   # measured float4 copy rate of the part (MI355X_MICROARCH.md): what a plan's byte floor is priced at
 
 
 def setup_workload(arch, scheme, batch, dev, seed, shard=None):
@@ -60,12 +68,15 @@ def golden_parity(arch, scheme, batch, seed, logits, lo=0):
     return bool(np.array_equal(y, fx["logits"][lo:lo + y.shape[0]]))
 
 
-def timed_steps(eng, steps, warmup, world, gathered):
+def timed_steps(eng, steps, warmup, world, batch_total=None):
     """W untimed + K timed steps on the engine stream; returns (wall seconds, GPU ms per step, block stats).
-    Block stats: the K steps are cut into >= 10 blocks (HIP events recorded between steps, no synchronisation) so that
-    a run reports mean +- std of the per-step time (tvm_benchmark/test_resnet_inference_time.py:257-271 protocol)."""
+    With an initialised process group every step ends with the logits gather of the multi-GPU path
+    (hawq_amd.dist.gather_logits into a preallocated tensor); the wall time is then the MAX over ranks.  Block stats: the
+    K steps are cut into >= 10 blocks (HIP events recorded between steps, no synchronisation) so that a run reports mean
+    +- std of the per-step time (tvm_benchmark/test_resnet_inference_time.py:257-271 protocol)."""
     import torch.distributed as dist
     from hawq_amd import _lib
+    from hawq_amd.dist import gather_logits
 
     sp = eng.stream.cuda_stream
     ev0, ev1 = C.c_void_p(), C.c_void_p()
@@ -73,11 +84,12 @@ def timed_steps(eng, steps, warmup, world, gathered):
     _lib.call("hawq_event_create", C.byref(ev1))
     blk = max(1, steps // 10)
     marks = []
+    gathered = torch.empty(world * eng.logits.shape[0], eng.logits.shape[1], device=eng.logits.device) if world > 1 else None
 
     def step():
         eng.run_resident()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, eng.logits)
+            gather_logits(eng.logits, batch_total, out=gathered)
 
     with torch.cuda.stream(eng.stream):
         for _ in range(warmup):
@@ -118,61 +130,95 @@ def timed_steps(eng, steps, warmup, world, gathered):
     std = (sum((v - mean) ** 2 for v in per_block) / max(n - 1, 1)) ** 0.5
     stats = dict(blocks=n, steps_per_block=blk, mean_ms=round(mean, 4), std_ms=round(std, 4),
                  min_ms=round(min(per_block), 4), max_ms=round(max(per_block), 4))
-    return t1 - t0, total / steps, stats
+    wall = t1 - t0
+    if world > 1:   # the contract's clock: MAX over ranks
+        t = torch.tensor([wall], device=eng.logits.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, total / steps, stats
 
 
-def cpu_baseline(model, x, gpu_logits, budget_s=25.0):
-    """Time the CPU fake-quant port (oracle/fakequant_port.py: the reference's frozen forward with its cost structure -
-    per-forward BN fold + weight re-quantisation + Decimal batch_frexp) on the host cores at the FULL batch of the
-    workload (B = 128): one warm-up forward of 2 images (thread pools, oneDNN primitives), then whole
-    forwards until `budget_s` is used (at least 1, at most 3); its logits double as a parity check of the GPU result."""
+def cpu_baseline(model, x, gpu_logits, sample=16, runs=3):
+    """The CPU fake-quant port (oracle/fakequant_port.py: the reference's frozen forward with its cost structure -
+    per-forward BN fold + weight re-quantisation + Decimal batch_frexp) on the host cores, SURVEY 8(d) protocol scaled to a
+    bounded sample: a quick thread-count sweep (8 / 32 / all cores on 4 images), one warm-up, then `runs` timed forwards of
+    the first `sample` images of the SAME batch; its logits double as a parity check of the GPU result.  Secondary baseline
+    (SURVEY 8(d)): the same port with its tensors on the MI355X (`.cuda()`, fp32 MIOpen / rocBLAS path)."""
     from oracle import fakequant_port, oracle
 
     st = oracle.extract_float_state(model)
-    xs = x.cpu()
+    xs = x[:sample].cpu()
+    all_threads = torch.get_num_threads()
+    sweep = {}
+    for nt in sorted({min(8, all_threads), min(32, all_threads), all_threads}):
+        torch.set_num_threads(nt)
+        fakequant_port.forward(st, xs[:2])
+        t0 = time.perf_counter()
+        fakequant_port.forward(st, xs[:4])
+        sweep[nt] = 4 / (time.perf_counter() - t0)
+    best_nt = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
     fakequant_port.forward(st, xs[:2])
-    runs, y = [], None
-    while len(runs) < 3 and (not runs or sum(runs) + runs[-1] <= budget_s):
+    secs, y = [], None
+    for _ in range(runs):
         t0 = time.perf_counter()
         y = fakequant_port.forward(st, xs)
-        runs.append(time.perf_counter() - t0)
+        secs.append(time.perf_counter() - t0)
+    torch.set_num_threads(all_threads)
     n = xs.shape[0]
-    parity = bool(torch.equal(y, gpu_logits.cpu()))
-    return dict(value=round(n * len(runs) / sum(runs), 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{len(runs)} whole forward(s) of the same batch of {n} after a 2-image warm-up (torch-CPU fp32 "
-                       f"fake-quant port of the reference path; seconds per forward: {[round(r, 1) for r in runs]})",
-                gpu_logits_bit_equal=parity, images_compared=n)
+    med = sorted(secs)[len(secs) // 2]
+    out = dict(value=round(n / med, 3), unit="images/s", cores=best_nt, kind="port",
+               sample=f"{runs} timed forwards (median) of the first {n} images of the benchmarked batch after a thread-count sweep "
+                      f"{ {k: round(v, 2) for k, v in sweep.items()} } img/s on 4 images and a 2-image warm-up (torch-CPU fp32 fake-quant port of "
+                      f"the reference path; seconds per forward: {[round(r, 2) for r in secs]})",
+               gpu_logits_bit_equal=bool(torch.equal(y, gpu_logits[:n].cpu())), images_compared=n)
+    try:   # the port with its tensors on the GPU: what `model.cuda()` of the reference's own path costs on this part
+        dev = gpu_logits.device
+        xg = x[:32]
+        fakequant_port.forward(st, xg[:2], dev)
+        torch.cuda.synchronize()
+        gs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            yg = fakequant_port.forward(st, xg, dev)
+            torch.cuda.synchronize()
+            gs.append(time.perf_counter() - t0)
+        out["port_on_gpu"] = dict(value=round(xg.shape[0] / sorted(gs)[1], 2), unit="images/s", images=int(xg.shape[0]),
+                                  seconds=[round(g, 3) for g in gs], logits_equal_integer_path=bool(torch.equal(yg, gpu_logits[:xg.shape[0]])),
+                                  note="fp32 fake-quant port, tensors on the MI355X (torch / MIOpen fp32 convs, host Decimal frexp per layer)")
+    except Exception as exc:  # a secondary figure must never take the bench line down
+        out["port_on_gpu"] = f"failed: {type(exc).__name__}: {exc}"
+    return out
+
+
+def plan_rows(arch, scheme):
+    """fused-plan byte model rows by layer name (hawq_amd/roofline.py:fused_plan_table)"""
+    from hawq_amd import roofline
+    return {r["name"].split("+")[0]: r for r in roofline.fused_plan_table(arch, scheme)}
 
 
 def launch_model(name, rows, batch):
-    """(algorithmic bytes, MACs) of one launch for `batch` images: the canonical per-layer model
-    (hawq_amd/roofline.py:layer_table) summed over the layers the launch covers."""
-    parts = []
-    base = name.split("+")[0]
-    if base in rows:
-        parts.append(rows[base])
-    if name.endswith("+identity"):
-        parts.append(rows[base.rsplit(".", 1)[0] + ".quant_identity_convbn"])
-    for extra in name.split("+")[1:]:   # a fused launch covers a second layer (expand conv + next unit's reduce conv)
+    """(bytes the launch has to move, MACs) for `batch` images from the FUSED plan's byte model: a fused expand -> reduce
+    launch covers two rows and never moves the 8-bit tensor between them (the first row's write of it, the second row's read)."""
+    parts = [p for p in name.split("+") if p != "identity"]
+    if parts[0] not in rows:
+        return 0, 0
+    r = rows[parts[0]]
+    byt = (r["read"] + r["write"]) * batch + r["weight_bytes"]
+    mac = r["macs"] * batch
+    for extra in parts[1:]:
         if extra in rows:
-            parts.append(rows[extra])
-    if name in ("hawq_quantize_input", "hawq_stem_fused"):
-        parts.append(rows["quant_input"])
-    if name in ("hawq_stem_conv7", "hawq_stem_fused"):
-        parts += [r for k, r in rows.items() if k.startswith("quant_init")]
-    if name == "hawq_avgpool_requant":
-        parts.append(rows["final_pool+quant_act_output"])
-    return (sum(r["act_bytes"] for r in parts) * batch + sum(r["weight_bytes"] for r in parts),
-            sum(r["macs"] for r in parts) * batch)
+            e = rows[extra]
+            byt += (e["write"] - e["read"]) * batch + e["weight_bytes"]
+            mac += e["macs"] * batch
+    return byt, mac
 
 
 def write_per_op(path, ops, rows, batch):
-    """Per-launch table: measured ms vs the canonical byte/MAC model of the layers each launch covers."""
-    def model(name):
-        return launch_model(name, rows, batch)
-    lines = ["| launch | ms | model MB | GB/s | % of 8 TB/s | GMAC | TOPS |", "|---|---|---|---|---|---|---|"]
+    """Per-launch table: measured ms vs the fused plan's byte / MAC model of the layers each launch covers."""
+    lines = ["| launch | ms | plan MB | GB/s | % of 8 TB/s | GMAC | TOPS |", "|---|---|---|---|---|---|---|"]
     for n, ms in ops:
-        b, mc = model(n)
+        b, mc = launch_model(n, rows, batch)
         lines.append(f"| {n} | {ms:.4f} | {b / 1e6:.1f} | {b / ms / 1e6:.0f} | {b / ms / 1e6 / 80:.1f} | {mc / 1e9:.2f} | "
                      f"{2 * mc / ms / 1e9:.0f} |")
     lines.append(f"\nsum of launches {sum(ms for _, ms in ops):.4f} ms")
@@ -199,25 +245,87 @@ class _stdout_to_stderr:
         return False
 
 
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def rccl_world1_selfcheck(dev, logits):
-    """Run the gather path (hawq_amd.dist.gather_logits -> all_gather_into_tensor) once through RCCL in a world of ONE
-    rank, so that the collective code has executed on this GPU even in the N = 1 bench run.  Outside the timed region."""
-    import socket
+    """Run the product's gather function (hawq_amd.dist.gather_logits -> all_gather_into_tensor) once through RCCL in a
+    world of ONE rank, so that the collective code has executed on this GPU even in the N = 1 bench run.  Outside the
+    timed region."""
     import torch.distributed as dist
+    from hawq_amd.dist import gather_logits
     try:
         with _stdout_to_stderr():
-            with socket.socket() as sk:
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-            out = torch.empty_like(logits)
-            dist.all_gather_into_tensor(out, logits.contiguous())
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+            out = gather_logits(logits)   # an initialised group of one rank still runs the collective
             torch.cuda.synchronize()
-            ok = bool(torch.equal(out, logits))
+            ok = bool(out.data_ptr() != logits.data_ptr() and torch.equal(out, logits))
             dist.destroy_process_group()
         return ok
     except Exception as exc:  # never let a rendezvous problem take the bench line down
         return f"failed: {type(exc).__name__}: {exc}"
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_main(args, rank, world):
+    """The N > 1 plumbing on CPU: gloo process group, stand-in forward (per-image independent, like the frozen network),
+    weak and strong decomposition, gather through hawq_amd.dist.gather_logits, MAX-over-ranks clock, one JSON line."""
+    import torch.distributed as dist
+    from hawq_amd.dist import gather_logits, shard_bounds
+    dist.init_process_group("gloo")
+    world_seen = dist.get_world_size()
+    if world_seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world_seen} ranks")
+    w = torch.randn(3 * 8 * 8, 10, generator=torch.Generator().manual_seed(0))
+
+    def fwd(x):
+        return x.reshape(x.shape[0], -1) @ w
+
+    def run(strong):
+        seed = 1 if strong else 1 + rank
+        x = torch.randn(args.batch, 3, 8, 8, generator=torch.Generator().manual_seed(seed))
+        lo, hi = shard_bounds(args.batch, rank, world) if strong else (0, args.batch)
+        for _ in range(args.warmup):
+            gather_logits(fwd(x[lo:hi]), args.batch if strong else None)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            full = gather_logits(fwd(x[lo:hi]), args.batch if strong else None)
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if strong:    # every rank checks the gathered batch against the single-process result
+            ok = torch.equal(full, fwd(x))
+        else:         # ... its own block of the gathered tensor against its own forward
+            ok = torch.equal(full[rank * args.batch:(rank + 1) * args.batch], fwd(x)) and full.shape[0] == world * args.batch
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        images = args.batch if strong else world * args.batch
+        return dict(value=round(images * args.steps / float(t.item()), 1), ms_per_step=round(float(t.item()) / args.steps * 1e3, 4),
+                    global_batch=images, batch_per_gpu=hi - lo, every_rank_parity=bool(flag.item()))
+
+    res = {"weak": run(False), "strong": run(True)}
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec", "value": res[args.scaling]["value"], "unit": "images/s", "n_gpus": world_seen,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": res[args.scaling]["ms_per_step"],
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+                          "data": "dry-spawn: CPU stand-in forward on gloo (launch / shard / gather plumbing only, not a measurement)",
+                          "config": {"workload": "dry_spawn_stub", "ranks_seen": world_seen, "backend": "gloo"},
+                          "weak": res["weak"], "strong": res["strong"]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -228,17 +336,22 @@ def main():
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--scheme", default="uniform8")
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (weak) / per job per step (strong)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which decomposition `value` reports (N > 1 measures both)")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads / per-kernel table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", default=None, help="write a per-launch roofline table (markdown) to this file")
+    ap.add_argument("--dry-spawn", action="store_true", help="CPU / gloo stand-in forward: exercises the N > 1 launch, shard, gather and report path")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_spawn:
+        return dry_main(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists)")
     torch.cuda.set_device(local)
@@ -251,37 +364,57 @@ def main():
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)   # communicator set-up (and RCCL's banner) happens at the first collective
             torch.cuda.synchronize()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but RCCL sees {dist.get_world_size()} ranks")
 
     from hawq_amd import roofline
     from hawq_amd.dist import shard_bounds
 
-    strong = args.scaling == "strong"
-    if strong and args.batch % world:
-        raise SystemExit("--scaling strong needs a batch divisible by the number of ranks")
-    lo, hi = shard_bounds(args.batch, rank, world) if strong else (0, args.batch)
-    seed = 1 if strong else 1 + rank
-    model, eng, x = setup_workload(args.arch, args.scheme, args.batch, dev, seed=seed, shard=(lo, hi) if strong else None)
-    local_batch = hi - lo
-    gathered = torch.empty(world * local_batch, eng.logits.shape[1], device=dev) if world > 1 else None
-    wall, gpu_ms, blocks = timed_steps(eng, args.steps, args.warmup, world, gathered)
-    if world > 1:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    if args.batch % world:
+        raise SystemExit("the batch must be divisible by the number of ranks (strong scaling shards ONE batch)")
+
+    def all_ranks(ok):   # a parity flag counts only if it holds on every rank
+        if world == 1 or ok is None:
+            return ok
+        f = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    # ---- weak: every rank its own batch (rank 0's is the fixture workload)
+    seed = 1 + rank
+    model, eng, x = setup_workload(args.arch, args.scheme, args.batch, dev, seed=seed)
+    local_batch = args.batch
+    wall, gpu_ms, blocks = timed_steps(eng, args.steps, args.warmup, world)
     overflow = eng.overflowed()
-    ms_per_step = wall / args.steps * 1e3
-    global_batch = args.batch if strong else world * args.batch
-    value = global_batch * args.steps / wall
-    parity = golden_parity(args.arch, args.scheme, args.batch, seed, eng.logits, lo)
+    parity = golden_parity(args.arch, args.scheme, args.batch, seed, eng.logits) if rank == 0 else None
+    runs = {"weak": dict(value=round(world * args.batch * args.steps / wall, 1), ms_per_step=round(wall / args.steps * 1e3, 4),
+                         global_batch=world * args.batch, batch_per_gpu=args.batch)}
+    # ---- strong (N > 1 only): ONE batch of `batch` images, rank r evaluates images shard_bounds(batch, r, N)
+    if world > 1:
+        lo, hi = shard_bounds(args.batch, rank, world)
+        m2, e2, x2 = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1, shard=(lo, hi))
+        w2, g2, b2 = timed_steps(e2, args.steps, args.warmup, world, batch_total=args.batch)
+        p2 = all_ranks(golden_parity(args.arch, args.scheme, args.batch, 1, e2.logits, lo))
+        runs["strong"] = dict(value=round(args.batch * args.steps / w2, 1), ms_per_step=round(w2 / args.steps * 1e3, 4),
+                              global_batch=args.batch, batch_per_gpu=hi - lo, gpu_ms_per_step=round(g2, 4),
+                              every_rank_logits_bit_equal_oracle=p2, concurrent_sub_batches=e2.chains)
+        del m2, e2, x2
+        torch.cuda.empty_cache()
+    scaling = args.scaling if args.scaling in runs else "weak"
+    head = runs[scaling]
 
     out = None
     if rank == 0:
         alg = roofline.algorithmic_bytes(args.arch, args.scheme, local_batch)
         macs = roofline.macs(args.arch, args.scheme, local_batch)
         gbs = alg / (gpu_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (counters cannot be collected in-process); valid for the
-        # tile / sub-batch choice and the git head recorded beside it
-        traffic, traffic_meta = None, None
+        fused_pairs = [n for n, v in eng.er_choice.items() if v and not n.endswith("@solo")]
+        plan_bytes = roofline.fused_plan_bytes(args.arch, args.scheme, local_batch, fused_pairs)
+        plan = dict(tiles=".".join(str(t) for t in eng.tile_choice.values()), fused_variants=".".join(str(t) for t in eng.er_choice.values()),
+                    chains=eng.chains)
+        # HBM bytes per launch from the committed PMC passes (counters cannot be collected in-process): recorded with the plan
+        # (tile ids / fused variants / chains) they were collected for; this run's plan is printed beside it
+        traffic, traffic_meta = None, {}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 traffic_meta = json.load(f).get(f"{args.arch}_{args.scheme}_b{local_batch}", {})
@@ -289,68 +422,78 @@ def main():
         except OSError:
             pass
         mfma_frac = 2 * macs / (gpu_ms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12)
-        fused_pairs = [n for n, v in eng.er_choice.items() if v and not n.endswith("@solo")]
         hbm_traffic_frac = traffic / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS if traffic else None
+        floor_ms = plan_bytes / (COPY_CEILING_GBS * 1e9) * 1e3
         out = {
-            "metric": "images/sec", "value": round(value, 1), "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "metric": "images/sec", "value": head["value"], "unit": "images/s", "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": f"{args.arch}_{args.scheme}_b{args.batch}", "arch": args.arch,
-                       "scheme": args.scheme, "batch_per_gpu": local_batch, "global_batch": global_batch,
+                       "scheme": args.scheme, "batch_per_gpu": head["batch_per_gpu"], "global_batch": head["global_batch"],
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
                        "residual_uint16_overflow": overflow,
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "exact_tie_requant_launches": eng.n_tie,
-                       "autotuned_tiles": ".".join(str(t) for t in eng.tile_choice.values()),
+                       "autotuned_tiles": plan["tiles"],
                        # candidate expand->reduce pairs: variant id of the fused launch, 0 = two separate launches were faster
-                       "fused_expand_reduce_launches": len(fused_pairs), "fused_variants": ".".join(str(t) for t in eng.er_choice.values()),
+                       "fused_expand_reduce_launches": len(fused_pairs), "fused_variants": plan["fused_variants"],
                        "fused_pairs": fused_pairs,
                        # expand convs without a fusable successor that run the wave-private kernel (fused_wp.hip) alone
                        "wave_private_solo_launches": [n[:-5] for n, v in eng.er_choice.items() if v and n.endswith("@solo")],
                        # ms per forward of the independently tuned plans the engine chose between
                        "plan_trials_ms": getattr(eng, "plan_trials_ms", None),
+                       "chain_timing_ms": {str(k): round(v, 4) for k, v in getattr(eng, "chain_timing_ms", {}).items()},
                        "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(eng, "er_split_tiles", {}).values()),
                        "concurrent_sub_batches": eng.chains},
-            # all logits of this rank's images against the CPU oracle's golden logits of the same workload
+            # all logits of rank 0's images against the CPU oracle's golden logits of the same workload
             "parity": {"gpu_logits_bit_equal_oracle": parity, "images_compared": local_batch if parity is not None else 0,
                        "fixture": f"tests/golden/b128_{args.arch}_{args.scheme}.npz"},
             "timing": dict(blocks, gpu_ms_per_step=round(gpu_ms, 4),
-                           note="HIP events on the engine stream between steps of the ONE timed region"),
+                           note="HIP events on the engine stream between steps of the ONE timed region (weak run)"),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / roofline.HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": ("committed PMC passes (profiles/traffic.json, git head "
-                                            f"{traffic_meta.get('git_head', 'r01')}), not collected by this run") if traffic else None,
-                         # measured HBM bytes / time / 8 TB/s: the PHYSICAL bandwidth utilisation ("frac" prices the
+                                            f"{traffic_meta.get('git_head', '?')}), not collected by this run; FETCH_SIZE x 2 + WRITE_SIZE count "
+                                            "requests at the L2's memory side, Infinity-Cache hits included: an UPPER bound on HBM bytes "
+                                            "(calibration: profiles/r03_pmc_calibration.md)") if traffic else None,
+                         "traffic_plan": traffic_meta.get("plan") or traffic_meta.get("config"), "this_run_plan": plan,
+                         "traffic_plan_matches_this_run": (traffic_meta.get("plan") == plan) if traffic else None,
+                         # counter bytes / time / 8 TB/s: upper bound on the physical bandwidth utilisation ("frac" prices the
                          # canonical SURVEY 8(d) byte model, which the fused plan undercuts)
                          "hbm_traffic_frac": round(hbm_traffic_frac, 4) if hbm_traffic_frac else None,
-                         "limiter": "neither roofline: HBM and MFMA utilisation are both well below 1 - the forward is bound "
-                                    "by epilogue VALU, per-launch fill/drain and occupancy (DESIGN.md 5)",
+                         "bound_note": "the schema offers hbm | mfma: HBM is the nearer roofline (hbm_traffic_frac vs mfma_frac), but the "
+                                       "counters put the forward well below BOTH - see limiter and plan_floor_ratio",
+                         "limiter": "neither roofline: epilogue VALU (~14-17 instructions per residual output), per-launch latency of one "
+                                    "workgroup in stages 3-4, lock-step phases inside workgroups (DESIGN.md 5)",
                          "kernel": "one hipGraph launch = whole forward of one batch",
                          "gpu_ms_per_launch": round(gpu_ms, 4), "algorithmic_bytes_per_launch": alg,
-                         # what the fused plan must move at minimum (hawq_amd/roofline.py:fused_plan_table); "traffic"
-                         # is its measured counterpart
-                         "fused_plan_bytes_per_launch": roofline.fused_plan_bytes(args.arch, args.scheme, local_batch,
-                                                                                  fused_pairs),
+                         # what the fused plan must move at minimum (hawq_amd/roofline.py:fused_plan_table); "traffic" is its
+                         # measured counterpart; floor = those bytes at the measured copy ceiling of the part
+                         "fused_plan_bytes_per_launch": plan_bytes,
+                         "plan_floor_ms": round(floor_ms, 4), "plan_floor_ratio": round(gpu_ms / floor_ms, 3),
                          "mfma_frac": round(mfma_frac, 4)},
         }
+        if world > 1:
+            out["weak"], out["strong"] = runs["weak"], runs.get("strong")
         if (not args.no_extra or args.per_op) and world == 1:
             ops = eng.profile_ops()
             tot = sum(ms for _, ms in ops)
-            rows = {r["name"]: r for r in roofline.layer_table(args.arch, args.scheme)}
+            rows = plan_rows(args.arch, args.scheme)
             top = sorted(ops, key=lambda t: -t[1])[:8]
             # eager launches timed one by one; with concurrent sub-batches this is sub-batch 0 alone
             out["roofline"]["eager_sum_ms"] = round(tot, 4)
-            out["roofline"]["eager_sum_batch"] = args.batch if eng.chains == 1 else eng.subs[0]._batch[0]
+            nb = args.batch if eng.chains == 1 else eng.subs[0]._batch[0]
+            out["roofline"]["eager_sum_batch"] = nb
             out["roofline"]["top_launches"] = [{"name": n, "ms": round(ms, 4)} for n, ms in top]
-            # the single most expensive kernel launch against its own byte / MAC model
+            # the single most expensive kernel launch against the bytes / MACs the FUSED plan moves for it
             dn, dms = top[0]
-            db, dm = launch_model(dn, rows, out["roofline"]["eager_sum_batch"])
+            db, dm = launch_model(dn, rows, nb)
             out["roofline"]["dominant_launch"] = {
-                "name": dn, "ms": round(dms, 4), "batch": out["roofline"]["eager_sum_batch"],
-                "algorithmic_bytes": db, "achieved_GBps": round(db / dms / 1e6, 1),
+                "name": dn, "ms": round(dms, 4), "batch": nb,
+                "plan_bytes": db, "achieved_GBps": round(db / dms / 1e6, 1),
                 "hbm_frac": round(db / dms / 1e6 / roofline.HBM_PEAK_GBS, 4),
                 "mfma_frac": round(2 * dm / (dms * 1e-3) / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4)}
             if args.per_op:
-                write_per_op(args.per_op, ops, rows, out["roofline"]["eager_sum_batch"])
+                write_per_op(args.per_op, ops, rows, nb)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, x, eng.logits)
         else:
@@ -380,7 +523,7 @@ def main():
             if (arch, scheme) == (args.arch, args.scheme):
                 continue
             m2, e2, x2 = setup_workload(arch, scheme, args.batch, dev, seed=1)
-            w2, g2, b2 = timed_steps(e2, n2, 5, 1, None)
+            w2, g2, b2 = timed_steps(e2, n2, 5, 1)
             alg2 = roofline.algorithmic_bytes(arch, scheme, args.batch)
             extra[f"{arch}_{scheme}_b{args.batch}"] = {
                 "images_per_s": round(args.batch * n2 / w2, 1), "gpu_ms": round(g2, 4), "gpu_ms_std": b2["std_ms"],
@@ -394,7 +537,7 @@ def main():
         if args.batch == 128:
             for nb in (64, 32, 16):
                 m2, e2, x2 = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1, shard=(0, nb))
-                w2, g2, b2 = timed_steps(e2, n2, 5, 1, None)
+                w2, g2, b2 = timed_steps(e2, n2, 5, 1)
                 extra[f"{args.arch}_{args.scheme}_shard_b{nb}"] = {
                     "images_per_s": round(nb * n2 / w2, 1), "gpu_ms": round(g2, 4), "gpu_ms_std": b2["std_ms"],
                     "gpu_logits_bit_equal": golden_parity(args.arch, args.scheme, args.batch, 1, e2.logits),

@@ -6,7 +6,7 @@ import torch
 
 from .bit_schedules import get_bit_config
 from .q_resnet import apply_bit_config, quantize_arch_dict
-from .quant_modules import freeze_model
+from .quant_modules import freeze_model, trust_integer_buffers
 from .skeleton import build_float_resnet, init_synthetic
 
 
@@ -38,6 +38,7 @@ def calibrate(model, images: torch.Tensor):
     freeze_model(model)
     model.invalidate_engine()
     # ranges and integer buffers now come from the float parameters again, not from a quantized checkpoint
+    trust_integer_buffers(model, False)
     model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=False)
     return model
 
@@ -58,7 +59,8 @@ def load_quantized_checkpoint(model, ckpt, strict: bool = True):
     """Load a reference ``quantized_checkpoint.pth.tar`` (path or the already-loaded dict) into ``model`` (a
     ``Q_ResNet*`` with the matching bit configuration applied), freeze it and make its fused engine trust the
     integer buffers (``IntegerEngine(from_buffers=True)``): no float weights, BN statistics or calibration are
-    needed.  Returns the model.  ``strict`` requires every quantized module to find its entries."""
+    needed.  Returns the model.  A file that LACKS a tensor the integer path needs is always refused (running on placeholder
+    buffers would return garbage logits silently); ``strict=False`` only tolerates EXTRA entries the model has no use for."""
     if not isinstance(ckpt, dict):
         ckpt = torch.load(ckpt, map_location="cpu")
     missing = [g for g in _QCKPT_GROUPS if g not in ckpt]
@@ -95,6 +97,8 @@ def load_quantized_checkpoint(model, ckpt, strict: bool = True):
     freeze_model(model)
     model.eval()
     model.invalidate_engine()
+    # both consumers of the loaded integers: the per-module path (forward_modules, Q_MobileNetV2) and the fused engine
+    trust_integer_buffers(model, True)
     model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=True)
     return model
 
@@ -133,6 +137,7 @@ def load_checkpoint(model, ckpt, freeze: bool = True):
         model.eval()
     model.invalidate_engine()
     # the integer buffers are stale now (quant_train.py:309-316 drops them too): re-derive from the float parameters
+    trust_integer_buffers(model, False)
     model.engine_defaults = dict(getattr(model, "engine_defaults", {}), from_buffers=False)
     return model, missing, unexpected
 
@@ -153,6 +158,8 @@ def validate(model, loader, uint8: bool = False, mean=(0.485, 0.456, 0.406), std
         for images, target in loader:
             images = images.to(device, non_blocking=True)
             target = target.to(device, non_blocking=True)
+            if uint8 and not hasattr(model, "engine"):
+                raise NotImplementedError(f"uint8 image input needs the fused ResNet engine; {type(model).__name__} has none")
             output = model.engine().forward_uint8(images, mean, std) if uint8 else model(images)
             _, pred = output.topk(5, 1, True, True)
             correct = pred.t().eq(target.view(1, -1).expand(5, -1))

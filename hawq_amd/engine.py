@@ -501,6 +501,7 @@ class IntegerEngine:
         ops, keep = _OpList(), []
         self._conv_args, self._conv_names = [], []
         self.acc_taps = {}
+        self.res_taps = {}   # unit name -> (stored post-ReLU residual tensor of this plan, NHWC shape): parity tests read them back
         self.n_fast = self.n_conv = self.n_k0 = self.n_tie = 0  # how many conv launches run the fast-contract kernels (/ shift-free)
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
@@ -610,6 +611,7 @@ class IntegerEngine:
                     new_res = self._alloc(N * ho * wo * c.cout, rdt) if need_res else None
                     if new_res is not None:
                         a.res_out, a.res_out_bits = new_res.data_ptr(), self.res_bits
+                        self.res_taps[u['name']] = (new_res, (N, ho, wo, c.cout))
                     new_qa = None
                     if nxt is not None:
                         a.out_bits = nxt['a_bits']
@@ -1073,6 +1075,18 @@ class IntegerEngine:
         ``forward_uint8`` check and clear the flag themselves (``overflow_fallbacks`` counts the batches they redid with
         int32 residuals); callers of the raw ``run_resident`` (bench.py) read it here."""
         return bool(self.flags.item() & 1)
+
+    def residual(self, unit):
+        """The stored post-ReLU residual of `unit` ("stage2.unit3": the value of its quant_act_int32 after ReLU, quant_utils.py:456)
+        from the LAST forward of this plan, as an NCHW int32 numpy array over the whole batch (sub-batch chains concatenated);
+        None if the plan never stores it (the next unit opens a stage and reads only the 8-bit block input)."""
+        parts = []
+        for e in (self.subs or [self]):
+            if unit not in e.res_taps:
+                return None
+            t, shp = e.res_taps[unit]
+            parts.append(t.cpu().numpy().reshape(shp).astype(np.int32).transpose(0, 3, 1, 2))
+        return np.concatenate(parts, 0)
 
     def accumulators(self, name):
         """int32 NHWC accumulators of a tapped conv (keep_accumulators=True) as an NCHW numpy array."""

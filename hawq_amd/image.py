@@ -11,6 +11,7 @@ not against Pillow's output.  JPEG decoding stays on the host (any decoder that 
 """
 from __future__ import annotations
 
+import functools
 import math
 
 import numpy as np
@@ -57,16 +58,15 @@ def resize_crop_geometry(h: int, w: int, resize: int = 256, crop: int = 224):
     return oh, ow, int(round((oh - crop) / 2.0)), int(round((ow - crop) / 2.0))
 
 
-_COEFF_CACHE = {}
-
-
+@functools.lru_cache(maxsize=256)   # ImageNet validation has thousands of distinct (h, w): bound the device allocations
 def _coeffs_dev(in_size, out_size, lo, n, dev):
-    key = (in_size, out_size, lo, n, str(dev))
-    if key not in _COEFF_CACHE:
-        b, c, k = bilinear_coeffs(in_size, out_size)
-        _COEFF_CACHE[key] = (torch.from_numpy(np.ascontiguousarray(b[lo:lo + n])).to(dev), torch.from_numpy(np.ascontiguousarray(c[lo:lo + n])).to(dev), k,
-                             int(b[lo:lo + n, 0].min()), int((b[lo:lo + n, 0] + b[lo:lo + n, 1]).max()))
-    return _COEFF_CACHE[key]
+    """(bounds relative to the first input index read, coefficients, taps, first input index, one past the last) of output
+    indices lo .. lo+n-1, on `dev`"""
+    b, c, k = bilinear_coeffs(in_size, out_size)
+    b = np.ascontiguousarray(b[lo:lo + n]).copy()
+    first, last = int(b[:, 0].min()), int((b[:, 0] + b[:, 1]).max())
+    b[:, 0] -= first
+    return (torch.from_numpy(b).to(dev), torch.from_numpy(np.ascontiguousarray(c[lo:lo + n])).to(dev), k, first, last)
 
 
 def resize_center_crop(img: torch.Tensor, resize: int = 256, crop: int = 224) -> torch.Tensor:
@@ -80,20 +80,18 @@ def resize_center_crop(img: torch.Tensor, resize: int = 256, crop: int = 224) ->
         raise ValueError("image too small for the crop (torchvision pads here; ImageNet validation images never need it)")
     img = img.contiguous()
     dev, sp = img.device, torch.cuda.current_stream(img.device).cuda_stream
-    bv, cv, kv, y0, y1 = _coeffs_dev(h, oh, top, crop, dev)       # vertical taps of the crop rows: input rows y0 .. y1
-    bh, chh, kh, _, _ = _coeffs_dev(w, ow, left, crop, dev)
+    bv, cv, kv, y0, y1 = _coeffs_dev(h, oh, top, crop, str(dev))       # vertical taps of the crop rows: input rows y0 .. y1
+    bh, chh, kh, x0, _ = _coeffs_dev(w, ow, left, crop, str(dev))       # horizontal taps: bounds relative to input column x0
     # Pillow runs the horizontal pass first, on the input rows the vertical pass will read
     tmp = torch.empty(y1 - y0, crop, ch, dtype=torch.uint8, device=dev)
     if ow != w:
-        _lib.call("hawq_resample_u8", img.data_ptr(), w, ch, bh.data_ptr(), chh.data_ptr(), kh, crop, 1, y1 - y0, y0, tmp.data_ptr(), sp)
+        _lib.call("hawq_resample_u8", img.data_ptr() + x0 * ch, w, ch, bh.data_ptr(), chh.data_ptr(), kh, crop, 1, y1 - y0, y0, tmp.data_ptr(), sp)
     else:
         tmp.copy_(img[y0:y1, left:left + crop])
     if oh == h:
         return tmp[top - y0:top - y0 + crop].clone()
     out = torch.empty(crop, crop, ch, dtype=torch.uint8, device=dev)
-    bv_rel = bv.clone()
-    bv_rel[:, 0] -= y0   # tmp starts at input row y0
-    _lib.call("hawq_resample_u8", tmp.data_ptr(), crop, ch, bv_rel.data_ptr(), cv.data_ptr(), kv, crop, 0, crop, 0, out.data_ptr(), sp)
+    _lib.call("hawq_resample_u8", tmp.data_ptr(), crop, ch, bv.data_ptr(), cv.data_ptr(), kv, crop, 0, crop, 0, out.data_ptr(), sp)   # tmp starts at input row y0
     return out
 
 

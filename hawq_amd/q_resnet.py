@@ -101,7 +101,7 @@ class _QResNet(nn.Module):
         self.fused = True          # use the integer plan when frozen + eval + CUDA
         self._engine = None
         # new parameters / ranges make a cached plan (packed weights, tables, hipGraph) stale
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_engine())
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._on_state_dict_loaded())
 
     # -- structure helpers -------------------------------------------------------------------
     @property
@@ -129,6 +129,15 @@ class _QResNet(nn.Module):
 
     def invalidate_engine(self):
         self._engine = None
+
+    def _on_state_dict_loaded(self):
+        """load_state_dict brought new float parameters / ranges: the cached plan is stale, and so is any trust in integer
+        buffers loaded earlier from a quantized checkpoint (hawq_amd.api.load_quantized_checkpoint sets it again itself)."""
+        from .quant_modules import trust_integer_buffers
+        self.invalidate_engine()
+        trust_integer_buffers(self, False)
+        if getattr(self, "engine_defaults", None):
+            self.engine_defaults = dict(self.engine_defaults, from_buffers=False)
 
     # -- forward -------------------------------------------------------------------------------
     def forward_modules(self, x):

@@ -447,6 +447,10 @@ class QuantLinear(_IntConvMixin, Module):
         if getattr(self, "_prep_key", None) == key:
             return self._prep_bias_scale
         dev = self.weight.device
+        if getattr(self, "use_integer_buffers", False):   # integer weights / bias / scale as loaded, see QuantBnConv2d.prepare
+            bias_scale = self.fc_scaling_factor.detach().float().cpu().view(1, -1) * s_a.view(1, -1)
+            self._prep_key, self._prep_bias_scale = key, bias_scale.to(dev)
+            return self._prep_bias_scale
         w_int, s_w = quantize_weight_per_channel(self.weight, self.weight_bit, self.per_channel)
         self.fc_scaling_factor = s_w.to(dev)
         self.weight_integer = w_int.to(dev)
@@ -532,6 +536,17 @@ class QuantDropout(Module):
 
 
 _QUANT_TYPES = (QuantAct, QuantConv2d, QuantLinear, QuantBnConv2d)
+
+
+def trust_integer_buffers(model, flag: bool):
+    """Mark every weight-carrying quantized module of `model` as running on its LOADED integer buffers / scales
+    (quantized_checkpoint.pth.tar, quant_train.py:665-670) - or, ``flag`` False, as deriving them from its float parameters
+    again.  The module path (forward_modules, Q_MobileNetV2) reads this per module; the fused ResNet engine reads
+    ``model.engine_defaults['from_buffers']``: hawq_amd.api keeps both in step."""
+    for m in model.modules():
+        if isinstance(m, (QuantBnConv2d, QuantConv2d, QuantLinear)):
+            m.use_integer_buffers = bool(flag)
+            m._prep_key = None
 
 
 def freeze_model(model):

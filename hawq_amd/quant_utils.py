@@ -26,8 +26,9 @@ _SCRATCH = {}
 
 
 def _stat_scratch(device):
-    """Per-device scratch of the statistics kernels: [2 floats out | 260 uint32 state + histogram]."""
-    key = (device.type, device.index)
+    """Scratch of the statistics kernels, [2 floats out | 260 uint32 state + histogram], one per (device, current stream):
+    two QuantAct statistics calls on different streams of one device must not share the histogram / state words."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SCRATCH:
         _SCRATCH[key] = (torch.zeros(2, dtype=torch.float32, device=device), torch.zeros(264, dtype=torch.int32, device=device))
     return _SCRATCH[key]

@@ -22,11 +22,21 @@ import torch
 import torch.nn.functional as F
 
 
+_DEV = None   # None: CPU (the timed baseline); a torch.device: bench.py's secondary "port on the GPU" figure
+
+
+def _t(a):
+    t = torch.from_numpy(a)
+    return t if _DEV is None else t.to(_DEV)
+
+
 def _frexp(r):
+    dev = r.device
+    r = r.cpu()   # the reference does this D2H -> Decimal -> H2D round trip on every call too (quant_utils.py:202-213)
     m, e = np.frexp(r.reshape(-1).numpy())
     mm = np.array([int(Decimal(float(v) * (2 ** 31)).quantize(Decimal('1'), rounding=decimal.ROUND_HALF_UP))
                    for v in m])
-    return torch.from_numpy(mm).view(r.shape), torch.from_numpy(31. - e).view(r.shape)
+    return torch.from_numpy(mm).view(r.shape).to(dev), torch.from_numpy(31. - e).view(r.shape).to(dev)
 
 
 def _sym_scale(lo, hi, bits, per_channel):
@@ -36,7 +46,7 @@ def _sym_scale(lo, hi, bits, per_channel):
 
 
 def _act_scale(a):
-    lo, hi = torch.from_numpy(a["x_min"]), torch.from_numpy(a["x_max"])
+    lo, hi = _t(a["x_min"]), _t(a["x_max"])
     if a["mode"] == "symmetric":
         return _sym_scale(lo, hi, a["bits"], False)
     return torch.clamp(hi - lo, min=1e-8) / float(2 ** a["bits"] - 1)
@@ -50,8 +60,8 @@ def _quant(x, bits, scale):
 
 def _convbn(cb, x, s_a):
     """QuantBnConv2d frozen forward incl. the per-forward parameter work."""
-    w, g, b = torch.from_numpy(cb["w"]), torch.from_numpy(cb["gamma"]), torch.from_numpy(cb["beta"])
-    mean, var = torch.from_numpy(cb["mean"]), torch.from_numpy(cb["var"])
+    w, g, b = _t(cb["w"]), _t(cb["gamma"]), _t(cb["beta"])
+    mean, var = _t(cb["mean"]), _t(cb["var"])
     std = torch.sqrt((var + cb["eps"]).double()).float()  # correctly rounded (DESIGN.md "sqrt quirk")
     sf = g / std
     sw = w * sf.reshape(-1, 1, 1, 1)
@@ -84,9 +94,19 @@ def _fixedpoint(z, a, s_out, s_a, s_w, identity=None, s_ida=None, s_idw=None):
     return (branch(identity, s_ida, s_idw) + branch(z - identity, s_a, s_w)).float()
 
 
-def forward(st, x: torch.Tensor) -> torch.Tensor:
-    """Frozen fake-quant forward on CPU (torch fp32); x fp32 [N,3,H,W]; returns fp32 logits."""
-    one = torch.ones(1)
+def forward(st, x: torch.Tensor, dev=None) -> torch.Tensor:
+    """Frozen fake-quant forward (torch fp32) on CPU - or, ``dev`` a GPU, with every tensor on that device (the
+    reference's own `.cuda()` path; bench.py's secondary baseline); x fp32 [N,3,H,W]; returns fp32 logits."""
+    global _DEV
+    _DEV = dev
+    try:
+        return _forward(st, x if dev is None else x.to(dev))
+    finally:
+        _DEV = None
+
+
+def _forward(st, x):
+    one = torch.ones(1, device=x.device)
     with torch.no_grad():
         a = st["quant_input"]
         s = _act_scale(a)
@@ -127,7 +147,7 @@ def forward(st, x: torch.Tensor) -> torch.Tensor:
         s8 = _act_scale(a)
         x = (_fixedpoint(x, a, s8, s_prev, one) * s8).view(x.size(0), -1)
         fc = st["fc"]
-        w, b = torch.from_numpy(fc["w"]), torch.from_numpy(fc["b"])
+        w, b = _t(fc["w"]), _t(fc["b"])
         s_fc = _sym_scale(w.min(dim=1).values, w.max(dim=1).values, fc["bits"], True)
         w_int = _quant(w, fc["bits"], s_fc)
         bs = s_fc.view(1, -1) * s8.view(1, -1)

@@ -182,7 +182,8 @@ def kat_modules(qm):
     return out
 
 
-def net_fixture(arch, scheme, batch, image=None, light=False):
+def net_fixture(arch, scheme, batch, image=None, light=False, calib=None):
+    """`calib`: images the ranges are calibrated on (default: the evaluated batch itself, as in the b2 fixtures)."""
     from oracle import oracle  # only used for its IEEE host-prep, to express weight_integer as patches
 
     qr, qm, qu = ref_live.load_reference()
@@ -193,7 +194,7 @@ def net_fixture(arch, scheme, batch, image=None, light=False):
     for p in q.state_dict().values():
         h.update(np.ascontiguousarray(p.numpy()).tobytes())
     out["weights_sha"] = np.array(h.hexdigest())
-    ref_live.calibrate_and_freeze(q, x)
+    ref_live.calibrate_and_freeze(q, x if calib is None else calib)
     y, convs, lins = ref_live.forward_with_taps(q, x)
     out["logits"] = y.numpy()
     out["top1"] = y.argmax(1).numpy()

@@ -85,10 +85,55 @@ def test_bench_strong_scaling_shards_line_up_with_the_golden_logits():
     assert bench.golden_parity("resnet50", "uniform8", 64, 1, full[:64]) is None   # no fixture for other batches
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (it used to run ONE rank
+    silently).  --dry-spawn keeps the whole launch / rendezvous / shard / gather / MAX-over-ranks / one-JSON-line path and
+    replaces the network by a CPU stand-in on gloo."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-spawn", "--steps", "3", "--warmup", "1", "--batch", "8"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert d["weak"]["global_batch"] == 16 and d["weak"]["batch_per_gpu"] == 8 and d["weak"]["every_rank_parity"] is True
+    assert d["strong"]["global_batch"] == 8 and d["strong"]["batch_per_gpu"] == 4 and d["strong"]["every_rank_parity"] is True
+    assert d["value"] == d["weak"]["value"]
+    # a launcher that provides another world size than --gpus asks for is refused, not silently accepted
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-spawn"], cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _world1_worker(port, q):
+    import torch.distributed as dist
+    from hawq_amd.dist import gather_logits
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    x = torch.randn(5, 7)
+    y = gather_logits(x)
+    q.put(bool(y.data_ptr() != x.data_ptr() and torch.equal(x, y)))
+    dist.destroy_process_group()
+
+
+def test_gather_logits_runs_the_collective_in_a_world_of_one():
+    """an initialised group of one rank is NOT short-circuited: the product function itself issues the all_gather"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
 @pytest.mark.gpu
 def test_rccl_gather_executes_on_the_gpu_at_world_size_one():
     """The collective of the multi-GPU path (one all_gather of the logits over RCCL) executed for real, in a world of
-    one rank: hawq_amd.dist.gather_logits short-circuits there, so call the collective directly as bench.py does."""
+    one rank, through the product's own hawq_amd.dist.gather_logits (bench.rccl_world1_selfcheck)."""
     import bench
     x = torch.randn(128, 1000, device="cuda")
     assert bench.rccl_world1_selfcheck(torch.device("cuda", 0), x) is True

@@ -33,6 +33,23 @@ def test_benchmarked_configuration_is_bit_exact_at_batch_128(arch, scheme):
     assert not eng.overflowed() and int(fx["residual_max"]) < 65536
     assert np.array_equal(y, fx["logits"]), f"{int((y != fx['logits']).any(1).sum())} of 128 images differ"
     assert np.array_equal(y.argmax(1), fx["top1"])
+    # north_star asks for bit-exact pre-requant values, not only logits: every stored uint16 residual tensor of the BENCHMARKED
+    # plan - the un-clamped sum of the two separately requantised branches after ReLU (quant_utils.py:416-456) - is read back
+    # and compared with the oracle's SHA-256 per 16-image slice (the plan does not store the residual of a stage's last unit:
+    # the next unit's identity conv reads the 8-bit block input)
+    names = [str(n) for n in fx["residual_names"]]
+    s = int(fx["slice"])
+    checked = 0
+    for ui, n in enumerate(names):
+        unit = n[:-len(".quant_act_int32.q")]
+        r = eng.residual(unit)
+        if r is None:
+            continue
+        assert r.shape[0] == 128 and r.dtype == np.int32
+        for k in range(128 // s):
+            assert H.sha(r[k * s:(k + 1) * s]) == str(fx["residual_sha"][k][ui]), (unit, k)
+        checked += 1
+    assert checked >= len(names) - 3 and checked >= 5, checked
     # the public entry point (flag check + fresh tensor) agrees and needed no int32 fallback
     y2 = eng(x)
     assert y2.data_ptr() != eng.logits.data_ptr() and np.array_equal(y2.cpu().numpy(), y) and eng.overflow_fallbacks == 0
@@ -44,6 +61,47 @@ def test_benchmarked_configuration_is_bit_exact_at_batch_128(arch, scheme):
     names = [str(n) for n in fx["residual_names"]]
     assert [H.sha(tr[n].astype(np.int32)) for n in names] == [str(v) for v in fx["residual_sha"][-1]]
     print(f"{arch} {scheme}: chains {eng.chains}, tiles {'.'.join(str(t) for t in eng.tile_choice.values())}")
+
+
+@pytest.mark.parametrize("arch,scheme", CONFIGS)
+def test_benchmarked_plan_reproduces_the_live_reference_on_its_integer_checkpoint(arch, scheme):
+    """The exact comparison north_star's contract names - reference integer checkpoint in, reference logits out
+    (quant_train.py:625-674) - AT THE BENCHMARKED CONFIGURATION: tests/golden/b128live_*.npz (make_b128_live.py) holds what the
+    UNMODIFIED reference computes for the benchmark's weights / calibration batch on images [0, 16) of the benchmark batch
+    (its frozen ranges, its integer buffers, its logits).  Those buffers are loaded (from_buffers=True: nothing is re-derived
+    from float parameters, so torch-CPU's non-IEEE sqrt cannot matter) into the engine exactly as bench.py configures it -
+    hipGraph, autotuned tiles, fused pairs, chosen sub-batch chains, all 128 images resident - and the first 16 rows of the
+    logits must be the live reference's, bit for bit; the remaining rows must equal the oracle fixture whenever the
+    reference's integers are the IEEE ones (no weight patch, identical scales)."""
+    from hawq_amd.engine import IntegerEngine
+    from hawq_amd.quant_modules import freeze_model
+    from hawq_amd.skeleton import synthetic_images
+
+    live = H.load(f"b128live_{arch}_{scheme}.npz")
+    fx = H.load(f"b128_{arch}_{scheme}.npz")
+    lo, hi = int(live["slice_lo"]), int(live["slice_hi"])
+    x = synthetic_images(128, seed=int(live["seed"]))
+    assert H.sha(x[lo:hi].numpy()) == str(live["input_sha"])
+    model = H.build_model(arch, scheme)
+    H.load_reference_ranges(model, live)
+    freeze_model(model)
+    model.eval()
+    # IEEE preparation first (the fixture expresses weight_integer as patches on it):
+    IntegerEngine(model, use_graph=False, autotune=False, chains=1)   # fills the modules' integer buffers (host preparation)
+    npatch = H.load_reference_integer_ckpt(model, live)
+    eng = IntegerEngine(model, from_buffers=True, use_graph=True)     # bench.setup_workload's engine configuration
+    xd = x.cuda()
+    y = eng(xd).cpu().numpy()
+    with torch.cuda.stream(eng.stream):   # the shipped path: graph replay on the resident batch
+        eng.run_resident()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.logits.cpu().numpy(), y) and not eng.overflowed() and eng.overflow_fallbacks == 0
+    assert eng.use_graph and eng.autotune and eng._batch[0] == 128
+    ref = live["logits"]
+    assert np.array_equal(y[lo:hi], ref), f"{int((y[lo:hi] != ref).any(1).sum())} of {hi - lo} images differ from the live reference"
+    assert np.array_equal(y[lo:hi].argmax(1), live["top1"])
+    print(f"{arch} {scheme}: live-reference checkpoint, {npatch} patched weights, chains {eng.chains}, "
+          f"rows equal to the oracle fixture: {int((y == fx['logits']).all(1).sum())}/128")
 
 
 @pytest.mark.parametrize("batch", [16, 32, 64])

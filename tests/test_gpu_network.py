@@ -59,6 +59,7 @@ def test_network_matches_reference_golden(arch, scheme):
     # the IEEE-prepared paths agree with the reference too on these fixtures (sqrt quirk does not
     # flip any rounding here); top-1 must agree regardless
     if strict_ieee:
+        assert np.array_equal(y_int.cpu().numpy(), ref)   # same LOGITS as the reference on the six base fixtures
         assert np.array_equal(y_int.argmax(1).cpu().numpy(), fx["top1"])
         assert np.array_equal(y_mod.argmax(1).cpu().numpy(), fx["top1"])
     assert np.array_equal(y_int.cpu().numpy(), y_mod.cpu().numpy())
