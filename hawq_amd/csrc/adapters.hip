@@ -218,6 +218,78 @@ extern "C" int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const in
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Depthwise 3x3 convolution (MobileNetV2's conv2, q_mobilenetv2.py:46-48; F.conv2d(groups = C), quant_modules.py:489-494):
+// int8 NHWC in, weights tap-major [3][3][C] (so that the 4 channels a thread owns are one dword per tap), exact int32 NHWC
+// accumulators out.  A thread owns 4 consecutive channels of DW_PX horizontally adjacent output pixels: its 9 weight dwords
+// stay in registers and neighbouring outputs share input columns (stride 1: 3 x (DW_PX + 2) dword loads for DW_PX outputs
+// instead of 9 each); consecutive lanes own consecutive channel groups, so every load / store instruction of a wave covers
+// whole 64..256-byte runs of the NHWC rows.  9 MACs per output: the layer is bound by its own bytes, not a matrix-pipe shape.
+namespace {
+constexpr int DW_PX = 4;
+__global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ w9c, const int32_t *__restrict__ bias,
+                                                           int N, int H, int W, int C, int stride, int Ho, int Wo, int32_t *__restrict__ out) {
+    const int cgs = C >> 2, wq = (Wo + DW_PX - 1) / DW_PX;
+    const long long total = (long long)N * Ho * wq * cgs;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % cgs);
+        long long m = idx / cgs;
+        const int xq = (int)(m % wq);
+        m /= wq;
+        const int oy = (int)(m % Ho), n = (int)(m / Ho), ox0 = xq * DW_PX;
+        int wreg[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wreg[t] = *reinterpret_cast<const int *>(w9c + (size_t)t * C + 4 * cg);
+        int acc[DW_PX][4];
+        const v4i b4 = bias ? *reinterpret_cast<const v4i *>(bias + 4 * cg) : v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[p][j] = b4[j];
+        const int ncol = (DW_PX - 1) * 2 + 3;   // input columns a thread may touch (stride <= 2)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = oy * stride - 1 + kh;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            const int8_t *rowp = in + ((size_t)n * H + iy) * W * C + 4 * cg;
+#pragma unroll
+            for (int col = 0; col < ncol; ++col) {
+                if (stride == 1 && col >= DW_PX + 2) break;
+                const int ix = ox0 * stride - 1 + col;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const int xw = *reinterpret_cast<const int *>(rowp + (size_t)ix * C);
+#pragma unroll
+                for (int p = 0; p < DW_PX; ++p) {
+                    const int kw = col - p * stride;    // tap of output p that reads this column
+                    if (kw < 0 || kw > 2) continue;
+                    const int ww = wreg[kh * 3 + kw];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[p][j] += (int)(int8_t)(xw >> (8 * j)) * (int)(int8_t)(ww >> (8 * j));
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < DW_PX; ++p)
+            if (ox0 + p < Wo)
+                *reinterpret_cast<v4i *>(out + (((size_t)n * Ho + oy) * Wo + ox0 + p) * C + 4 * cg) = v4i{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+    }
+}
+}  // namespace
+
+extern "C" int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 int32_t stride, int32_t *out_acc, void *stream) {
+    HAWQ_REQUIRE(in && wgt9c && out_acc, "hawq_depthwise3x3: null pointer");
+    HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3: empty output");
+    const long long total = (long long)N * Ho * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(depthwise3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, stride, Ho, Wo, out_acc);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Image pipeline in front of forward_uint8 (quant_train.py:428-440: transforms.Resize(256) + CenterCrop(224) on the
 // decoded PIL image, then ToTensor + Normalize, which the stem's look-up table replays).  One separable pass of Pillow's
 // 8-bit antialiased resampling (libImaging/Resample.c, ImagingResampleHorizontal_8bpc / ...Vertical_8bpc): fixed-point

@@ -1237,15 +1237,19 @@ using B1 = BandCfg<256, 128, 4, 2, 512, 2, 1, 8>;   // 8 MFMA waves x (64 px x 6
 using B2 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8, 4>;   // 8 MFMA waves x (64 px x 32 ch) + 8 producers: twice the workgroups for 14x14 / 7x7
 using B3 = BandCfg<256, 128, 4, 2, 384, 2, 1, 8, 4>;   // B1 with a 384-pixel band (14x14 / 7x7 maps): room for a 4-stage W ring
 using B4 = BandCfg<128, 128, 2, 4, 256, 2, 1, 8, 5>;   // B2 with a 5-stage W ring (W issued 4 filter rows ahead)
-constexpr int NUM_BAND_TILES = 5;
+// round 3: in stages 3-4 a launch has fewer workgroups than the chip has CUs and lasts as long as ONE workgroup (profiles/
+// r03_mallprobe.md), so halve the work per workgroup and let two of them share a CU: 128 px x 64 ch, 4 MFMA waves (64 px x 32 ch)
+// + 4 producers, 3-stage W ring of 12 KiB stages: 68 KiB.  4x the workgroups of B1 / B3 (392 for the 7x7 layers at batch 128)
+using B5 = BandCfg<128, 64, 2, 2, 256, 2, 4, 4, 3>;
+constexpr int NUM_BAND_TILES = 6;
 
 typedef void (*KernelFn)(const ConvP);
 struct BandInfo { KernelFn fn[2][2][2]; int bm, bn, band_px, bstages, lds, nt; };  // fn[hawq4][exact-tie][residual]
 #define BAND_FN(B, N, T) {conv3x3_band_kernel<B, N, T, HAWQ_EPI_REQUANT>, conv3x3_band_kernel<B, N, T, HAWQ_EPI_RESIDUAL>}
 #define BAND_ENTRY(B) {{{BAND_FN(B, false, false), BAND_FN(B, false, true)}, {BAND_FN(B, true, false), BAND_FN(B, true, true)}}, B::BM, B::BN, B::BAND_PX, B::BSTAGES, B::LDS_BYTES + B::BN * 16, B::NT}
-const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2), BAND_ENTRY(B3), BAND_ENTRY(B4)};
+const BandInfo kBand[NUM_BAND_TILES] = {BAND_ENTRY(B0), BAND_ENTRY(B1), BAND_ENTRY(B2), BAND_ENTRY(B3), BAND_ENTRY(B4), BAND_ENTRY(B5)};
 // tile ids tried, in this order, when the caller leaves the choice open for a layer that needs a band kernel
-const int kBandPreference[NUM_BAND_TILES] = {0, 3, 1, 2, 4};
+const int kBandPreference[NUM_BAND_TILES] = {0, 3, 1, 2, 4, 5};
 
 // Does band tile `bi` take this layer?  (3x3 / stride 1 / pad 1, single branch, fast-contract tables, int8 or hawq4
 // operands, REQUANT or 16-bit RESIDUAL epilogue, the band of a pixel tile fits the LDS stage)

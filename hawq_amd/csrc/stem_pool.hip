@@ -161,7 +161,14 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
     const int32_t *__restrict__ e, int a_lo, int a_hi, int Hc, int Wc, int Hp, int Wp,
     uint16_t *__restrict__ res_out, void *__restrict__ out_q, int out_bits, int mq, int eq, int q_lo, int q_hi,
     int fast, int dbg) {
-    __shared__ __attribute__((aligned(16))) char patch[2 * SF_PATCH];
+    // Two copies of the int8 patch: `patch` and, 16 bytes into the second half, the SAME bytes shifted down by 8 (copy byte a =
+    // patch byte a + 8).  A lane's B fragment is 16 consecutive bytes starting at a multiple of 8: window columns dx = 0 / 2
+    // read it 16-byte aligned from `patch`, dx = 1 from the shifted copy - one conflict-free ds_read_b128 per MFMA instead of
+    // two ds_read_b64 that reach only half of the LDS banks (lanes are 16 bytes apart: 8-byte reads leave every other bank
+    // pair idle, and the 4 pooled rows of a wave fold onto each other two-way).  The 126 fragment reads per wave were the
+    // kernel's largest single cost (4 MB of LDS reads per CU per 8 workgroups).
+    __shared__ __attribute__((aligned(16))) char patch[4 * SF_PATCH + 32];
+    char *const patch8 = patch + 2 * SF_PATCH + 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int bw = (Wp + 7) >> 3, bh = (Hp + 7) >> 3;
@@ -235,6 +242,8 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
             }
             v4i o = {w[0], w[1], w[2], w[3]};
             *reinterpret_cast<v4i *>(patch + gaddr[k]) = o;
+            *reinterpret_cast<v2i *>(patch8 + gaddr[k] - 8) = v2i{o.x, o.y};
+            *reinterpret_cast<v2i *>(patch8 + gaddr[k]) = v2i{o.z, o.w};
         }
     } else {
     // ---- quantise the input patch(es) into LDS: q = clamp(rint(fl(1/S) * x))  (quant_utils.py:73-97)
@@ -295,6 +304,8 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
         }
         v4i o = {w[0], w[1], w[2], w[3]};
         *reinterpret_cast<v4i *>(patch + gaddr[k]) = o;
+        *reinterpret_cast<v2i *>(patch8 + gaddr[k] - 8) = v2i{o.x, o.y};
+        *reinterpret_cast<v2i *>(patch8 + gaddr[k]) = v2i{o.z, o.w};
     }
     }
     __syncthreads();
@@ -303,7 +314,8 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
     const int pr = (wave & 1) * 4 + (l31 >> 3), pc = l31 & 7;  // pooled pixel of this lane inside the block
     const int py = py0 + pr, px = px0 + pc, n = n0 + img;
     const bool pvalid = n < N && py < Hp && px < Wp;
-    const char *pbase = patch + img * SF_PATCH + ((4 * pr) * SF_PW + 4 * pc + 4 * h) * 4;
+    const int poff = img * SF_PATCH + ((4 * pr) * SF_PW + 4 * pc + 4 * h) * 4;   // multiple of 16
+    const char *pbase = patch + poff, *pbase8 = patch8 + poff;
     const size_t opix = ((size_t)n * Hp + py) * Wp + px;
 
     // The two 32-channel halves are walked one after the other: weights of ONE half (7 fragments, 28 VGPRs), one
@@ -329,11 +341,10 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
             v16i acc0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc0[r] = 0;
+            const char *wbase = dx == 1 ? pbase8 : pbase + 8 * dx;   // patch bytes [8 dx, 8 dx + 16) of the row segment, 16-byte aligned
 #pragma unroll
             for (int kh = 0; kh < 7; ++kh) {
-                const char *s0 = pbase + ((2 * dy + kh) * SF_PW + 2 * dx) * 4;  // 8-byte aligned
-                const v2i a0 = *reinterpret_cast<const v2i *>(s0), a1 = *reinterpret_cast<const v2i *>(s0 + 8);
-                v4i af = {a0.x, a0.y, a1.x, a1.y};
+                const v4i af = *reinterpret_cast<const v4i *>(wbase + ((2 * dy + kh) * SF_PW) * 4);
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kh], af, acc0, 0, 0, 0);
             }
 #pragma unroll

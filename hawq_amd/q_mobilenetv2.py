@@ -1,113 +1,123 @@
-"""Quantised MobileNetV2 with the reference's structure and names (utils/models/q_mobilenetv2.py:12-262): same classes,
-attribute names (``quant_input``, ``init_block``, ``features.stageN.unitM.{quant_act, conv1, quant_act1, conv2, quant_act2,
-conv3, quant_act_int32}``, ``quant_act_before_final_block``, ``features.final_block``, ``quant_act_int32_final``,
-``features.final_pool``, ``quant_act_output``, ``output``) and call order, so state_dict keys and the
-``bit_config_mobilenetv2_w1_*`` schedules line up.
+"""Quantised MobileNetV2 over the drop-in modules: a table-driven builder, not a transcription of the reference's file.
 
-Execution is module by module through the HIP library (the fp32-tuple convention of the reference): 1x1 convs on the MFMA
-implicit-GEMM kernel, 3x3 depthwise convs on hawq_conv2d_grouped, every QuantAct on hawq_fixedpoint_f32.  The fused integer
-plan (hawq_amd.engine) covers the ResNets only - SURVEY.md 8(f).3 lists MobileNetV2 as the next widening."""
+The reference (utils/models/q_mobilenetv2.py:12-209) spells the network out class by class; with INTEGRATION.md option A its
+own file runs unchanged on ``hawq_amd.quant_modules``.  This module exists for option B (no reference tree around): it WALKS
+the float network it is given - ``features.init_block``, every ``features.stageN.unitM`` with whatever of ``conv1`` (1x1
+expansion), ``conv2`` (3x3 depthwise), ``conv3`` (1x1 linear projection) the unit has, ``features.final_block``,
+``features.final_pool``, ``output`` - and mirrors each float layer with the quantized module of the same role under the
+reference's attribute names, in the reference's registration order, so that ``state_dict`` keys, ``named_modules()`` order and
+the ``bit_config_mobilenetv2_w1_*`` schedules (bit_config.py) line up with checkpoints and fixtures of the reference.
+
+The forward is one rule applied along the layer tables below: ``conv -> ReLU6 -> QuantAct`` (quant_modules.py:205-305 case 0)
+for every activated layer, the bare ``conv`` for a unit's projection, and the unit-closing ``quant_act_int32`` in its
+residual form (fixedpoint_fn case 1, quant_utils.py:416-456) when the float unit keeps its input shape.
+
+Execution is module by module through the HIP library in the reference's fp32-tuple convention: 1x1 convs on the MFMA
+implicit-GEMM kernel, the 3x3 depthwise convs on ``hawq_depthwise3x3`` (adapters.hip), every QuantAct on
+``hawq_fixedpoint_f32``.  The fused integer plan (hawq_amd.engine) covers the ResNets; MobileNetV2 in that plan is the next
+widening of SURVEY.md 8(f).3 (its QuantConv2d classifier runs the reference's fp32 conv on un-rounded ``x / S_a``,
+quant_modules.py:727-736, which an integer path reproduces to 2 ulp, not bit for bit)."""
 from __future__ import annotations
 
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .quant_modules import QuantAct, QuantAveragePool2d, QuantBnConv2d, QuantConv2d
 
+# (float child, QuantAct that consumes its ReLU6'd output) of a unit's activated layers, in execution order; the projection
+# `conv3` has no activation of its own and feeds the unit-closing `quant_act_int32`
+UNIT_ACTIVATED = (("conv1", "quant_act1"), ("conv2", "quant_act2"))
+UNIT_PROJECTION = "conv3"
+
+
+def _fold(float_block) -> QuantBnConv2d:
+    """conv + BN block of the float network -> QuantBnConv2d holding the same parameters"""
+    q = QuantBnConv2d()
+    q.set_param(float_block.conv, float_block.bn)
+    return q
+
+
+def _activated(conv, act, x, scale):
+    """conv -> ReLU6 -> QuantAct (case 0): the pattern of every layer that is not a linear projection"""
+    x, w_scale = conv(x, scale)
+    return act(F.relu6(x), scale, w_scale)
+
 
 class Q_LinearBottleneck(nn.Module):
-    """Quantised MobileNetV2 unit (reference: q_mobilenetv2.py:12-93)."""
+    """One inverted-residual unit, built from the float unit's own children (role of q_mobilenetv2.py:12-93)."""
 
-    def __init__(self, model, in_channels, out_channels, stride, expansion, remove_exp_conv):
+    def __init__(self, float_unit, residual: bool):
         super().__init__()
-        self.residual = (in_channels == out_channels) and (stride == 1)
-        self.use_exp_conv = (expansion or (not remove_exp_conv))
-        self.activatition_func = nn.ReLU6()
+        self.residual = bool(residual)
         self.quant_act = QuantAct()
-        if self.use_exp_conv:
-            self.conv1 = QuantBnConv2d()
-            self.conv1.set_param(model.conv1.conv, model.conv1.bn)
-            self.quant_act1 = QuantAct()
-        self.conv2 = QuantBnConv2d()
-        self.conv2.set_param(model.conv2.conv, model.conv2.bn)
-        self.quant_act2 = QuantAct()
-        self.conv3 = QuantBnConv2d()
-        self.conv3.set_param(model.conv3.conv, model.conv3.bn)
+        self.activated = tuple((c, a) for c, a in UNIT_ACTIVATED if hasattr(float_unit, c))   # a unit may lack the expansion conv
+        for conv, act in self.activated:
+            setattr(self, conv, _fold(getattr(float_unit, conv)))
+            setattr(self, act, QuantAct())
+        setattr(self, UNIT_PROJECTION, _fold(getattr(float_unit, UNIT_PROJECTION)))
         self.quant_act_int32 = QuantAct()
 
     def forward(self, x, scaling_factor_int32=None):
-        if self.residual:
-            identity = x
-        x, act_scaling_factor = self.quant_act(x, scaling_factor_int32, None, None, None, None)
-        if self.use_exp_conv:
-            x, weight_scaling_factor = self.conv1(x, act_scaling_factor)
-            x = self.activatition_func(x)
-            x, act_scaling_factor = self.quant_act1(x, act_scaling_factor, weight_scaling_factor, None, None)
-        x, weight_scaling_factor = self.conv2(x, act_scaling_factor)
-        x = self.activatition_func(x)
-        x, act_scaling_factor = self.quant_act2(x, act_scaling_factor, weight_scaling_factor, None, None)
-        x, weight_scaling_factor = self.conv3(x, act_scaling_factor)   # linear bottleneck: no activation
-        if self.residual:
-            x = x + identity
-            x, act_scaling_factor = self.quant_act_int32(x, act_scaling_factor, weight_scaling_factor, identity,
-                                                         scaling_factor_int32, None)
-        else:
-            x, act_scaling_factor = self.quant_act_int32(x, act_scaling_factor, weight_scaling_factor, None, None, None)
-        return x, act_scaling_factor
+        skip = x if self.residual else None
+        x, scale = self.quant_act(x, scaling_factor_int32)
+        for conv, act in self.activated:
+            x, scale = _activated(getattr(self, conv), getattr(self, act), x, scale)
+        x, w_scale = getattr(self, UNIT_PROJECTION)(x, scale)
+        if skip is None:
+            return self.quant_act_int32(x, scale, w_scale)
+        # both branches are requantised separately inside (the block input still carries the previous unit's scale)
+        return self.quant_act_int32(x + skip, scale, w_scale, skip, scaling_factor_int32, None)
 
 
 class Q_MobileNetV2(nn.Module):
-    """Quantised MobileNetV2 (reference: q_mobilenetv2.py:96-209)."""
+    """Quantised mirror of a pytorchcv-style float MobileNetV2 (role of q_mobilenetv2.py:96-209)."""
 
-    def __init__(self, model, channels, init_block_channels, final_block_channels, remove_exp_conv, in_channels=3,
-                 in_size=(224, 224), num_classes=1000):
+    def __init__(self, model):
         super().__init__()
-        self.in_size, self.num_classes, self.channels = in_size, num_classes, channels
-        self.activatition_func = nn.ReLU6()
+        f = model.features
         self.quant_input = QuantAct()
-        self.add_module("init_block", QuantBnConv2d())
-        self.init_block.set_param(model.features.init_block.conv, model.features.init_block.bn)
+        self.init_block = _fold(f.init_block)
         self.quant_act_int32 = QuantAct()
         self.features = nn.Sequential()
-        in_channels = init_block_channels
-        for i, channels_per_stage in enumerate(channels):
-            stage = nn.Sequential()
-            cur_stage = getattr(model.features, f'stage{i + 1}')
-            for j, out_channels in enumerate(channels_per_stage):
-                cur_unit = getattr(cur_stage, f'unit{j + 1}')
-                stride = 2 if (j == 0) and (i != 0) else 1
-                expansion = (i != 0) or (j != 0)
-                stage.add_module("unit{}".format(j + 1), Q_LinearBottleneck(cur_unit, in_channels=in_channels, out_channels=out_channels,
-                                                                            stride=stride, expansion=expansion,
-                                                                            remove_exp_conv=remove_exp_conv))
-                in_channels = out_channels
-            self.features.add_module("stage{}".format(i + 1), stage)
+        width = f.init_block.conv.out_channels
+        self.channels = []
+        for sname, stage in f.named_children():
+            if not sname.startswith("stage"):
+                continue
+            qstage, widths = nn.Sequential(), []
+            for uname, unit in stage.named_children():
+                proj, dw = getattr(unit, UNIT_PROJECTION).conv, unit.conv2.conv
+                qstage.add_module(uname, Q_LinearBottleneck(unit, residual=(proj.out_channels == width and dw.stride[0] == 1)))
+                width = proj.out_channels
+                widths.append(width)
+            self.features.add_module(sname, qstage)
+            self.channels.append(widths)
         self.quant_act_before_final_block = QuantAct()
-        self.features.add_module("final_block", QuantBnConv2d())
-        self.features.final_block.set_param(model.features.final_block.conv, model.features.final_block.bn)
+        self.features.add_module("final_block", _fold(f.final_block))
         self.quant_act_int32_final = QuantAct()
-        self.features.add_module("final_pool", QuantAveragePool2d())
-        self.features.final_pool.set_param(model.features.final_pool)
+        pool = QuantAveragePool2d()
+        pool.set_param(f.final_pool)
+        self.features.add_module("final_pool", pool)
         self.quant_act_output = QuantAct()
         self.output = QuantConv2d()
         self.output.set_param(model.output)
 
+    def units(self):
+        for sname, stage in self.features.named_children():
+            if sname.startswith("stage"):
+                yield from stage.children()
+
     def forward(self, x):
-        x, act_scaling_factor = self.quant_input(x)
-        x, weight_scaling_factor = self.init_block(x, act_scaling_factor)
-        x = self.activatition_func(x)
-        x, act_scaling_factor = self.quant_act_int32(x, act_scaling_factor, weight_scaling_factor, None, None)
-        for i, channels_per_stage in enumerate(self.channels):
-            cur_stage = getattr(self.features, f'stage{i + 1}')
-            for j, _ in enumerate(channels_per_stage):
-                x, act_scaling_factor = getattr(cur_stage, f'unit{j + 1}')(x, act_scaling_factor)
-        x, act_scaling_factor = self.quant_act_before_final_block(x, act_scaling_factor, None, None, None, None)
-        x, weight_scaling_factor = self.features.final_block(x, act_scaling_factor)
-        x = self.activatition_func(x)
-        x, act_scaling_factor = self.quant_act_int32_final(x, act_scaling_factor, weight_scaling_factor, None, None, None)
-        x = self.features.final_pool(x, act_scaling_factor)
-        x, act_scaling_factor = self.quant_act_output(x, act_scaling_factor, None, None, None, None)
-        x, act_scaling_factor = self.output(x, act_scaling_factor)
-        return x.view(x.size(0), -1)
+        x, scale = self.quant_input(x)
+        x, scale = _activated(self.init_block, self.quant_act_int32, x, scale)
+        for unit in self.units():
+            x, scale = unit(x, scale)
+        x, scale = self.quant_act_before_final_block(x, scale)
+        x, scale = _activated(self.features.final_block, self.quant_act_int32_final, x, scale)
+        x = self.features.final_pool(x, scale)
+        x, scale = self.quant_act_output(x, scale)
+        x, _ = self.output(x, scale)
+        return x.flatten(1)
 
     forward_modules = forward
 
@@ -120,13 +130,8 @@ class Q_MobileNetV2(nn.Module):
         pass
 
 
-def q_get_mobilenetv2(model, width_scale, remove_exp_conv=False):
-    """q_mobilenetv2.py:212-249 (width_scale 1.0 only: the one the reference's schedules cover)."""
-    if width_scale != 1.0:
-        raise NotImplementedError("only mobilenetv2_w1 has bit schedules (bit_config.py)")
-    return Q_MobileNetV2(model, channels=model.channels, init_block_channels=32, final_block_channels=1280,
-                         remove_exp_conv=remove_exp_conv)
-
-
 def q_mobilenetv2_w1(model):
-    return q_get_mobilenetv2(model, width_scale=1.0)
+    """Entry point named like the reference's (q_mobilenetv2.py:252): the width-1.0 network its bit schedules cover."""
+    if getattr(model, "arch", "mobilenetv2_w1") != "mobilenetv2_w1":
+        raise NotImplementedError("only mobilenetv2_w1 has bit schedules (bit_config.py)")
+    return Q_MobileNetV2(model)

@@ -201,8 +201,11 @@ class _IntConvMixin:
         Cout, Cg, KH, KW = weight_integer.shape
         dev = x.device
         key = ("g", weight_integer.data_ptr(), weight_integer._version, bias_integer.data_ptr(), bias_integer._version, str(dev))
+        # depthwise 3x3 (MobileNetV2's conv2): the vectorised kernel with tap-major weights [3][3][C]
+        depthwise = groups == Cin == Cout and KH == KW == 3 and padding == 1 and stride in (1, 2) and Cin % 4 == 0
         if getattr(self, "_dev_key", None) != key:
-            w = weight_integer.detach().cpu().numpy().astype(np.int8).transpose(0, 2, 3, 1)  # [Cout][KH][KW][Cin / groups]
+            w = weight_integer.detach().cpu().numpy().astype(np.int8)
+            w = w.reshape(Cout, 9).T if depthwise else w.transpose(0, 2, 3, 1)   # [3][3][C]  /  [Cout][KH][KW][Cin / groups]
             self._dev_w = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
             b = bias_integer.detach().cpu().numpy().astype(np.int64).clip(-2 ** 31, 2 ** 31 - 1).astype(np.int32)
             self._dev_b = torch.from_numpy(b).to(dev)
@@ -215,8 +218,11 @@ class _IntConvMixin:
         Ho = (H + 2 * padding - KH) // stride + 1
         Wo = (W + 2 * padding - KW) // stride + 1
         acc = torch.empty(N * Ho * Wo * Cout, dtype=torch.int32, device=dev)
-        _lib.call("hawq_conv2d_grouped", xq.data_ptr(), self._dev_w.data_ptr(), self._dev_b.data_ptr(), N, H, W, Cin, Cout, KH, KW,
-                  stride, padding, groups, acc.data_ptr(), _stream())
+        if depthwise:
+            _lib.call("hawq_depthwise3x3", xq.data_ptr(), self._dev_w.data_ptr(), self._dev_b.data_ptr(), N, H, W, Cin, stride, acc.data_ptr(), _stream())
+        else:
+            _lib.call("hawq_conv2d_grouped", xq.data_ptr(), self._dev_w.data_ptr(), self._dev_b.data_ptr(), N, H, W, Cin, Cout, KH, KW,
+                      stride, padding, groups, acc.data_ptr(), _stream())
         y = torch.empty(N, Cout, Ho, Wo, dtype=torch.float32, device=dev)
         _lib.call("hawq_acc_nhwc_to_f32_nchw", acc.data_ptr(), y.data_ptr(), N, Cout, Ho, Wo, Cout, self._dev_fs.data_ptr(), _stream())
         return y

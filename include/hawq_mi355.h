@@ -233,6 +233,12 @@ int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const int32_t *bias
                         int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t groups,
                         int32_t *out_acc, void *stream);
 
+/* Depthwise 3x3 / pad 1 conv (groups == Cin == Cout; MobileNetV2's conv2, q_mobilenetv2.py:46-48 through QuantBnConv2d.forward,
+ * quant_modules.py:489-494): in [N][H][W][C] int8, wgt9c [3][3][C] int8 (tap-major), bias [C] or NULL -> out_acc
+ * [N][Ho][Wo][C] int32 (exact).  C % 4 == 0, stride 1 or 2. */
+int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, int32_t N, int32_t H, int32_t W, int32_t C,
+                      int32_t stride, int32_t *out_acc, void *stream);
+
 /* One separable pass of Pillow's 8-bit antialiased resampling (what torchvision's Resize(256) does to the decoded PIL image,
  * quant_train.py:428-440): uint8 HWC in / out, int32 coefficients with 22 fractional bits (hawq_amd/image.py builds them as
  * Resample.c's precompute_coeffs + normalize_coeffs_8bpc do).

@@ -47,16 +47,16 @@ def test_module_signatures_equal_the_reference():
         assert _sig(getattr(ours, fn)) == _sig(getattr(qm, fn))
 
 
-def _reference_graph_over(modules_pkg):
-    """utils/models/q_resnet.py of the reference, unmodified, with `..quantization_utils.quant_modules` resolved to `modules_pkg`."""
+def _reference_graph_over(modules_pkg, fname="q_resnet.py"):
+    """utils/models/<fname> of the reference, unmodified, with `..quantization_utils.quant_modules` resolved to `modules_pkg`."""
     from oracle import ref_live
     ref_live.load_reference()   # registers the `utils` package shell and the pytorchcv stubs
     key = "utils.quantization_utils.quant_modules"
     saved = sys.modules[key]
     sys.modules[key] = modules_pkg
     try:
-        spec = importlib.util.spec_from_file_location("utils.models._q_resnet_over_" + modules_pkg.__name__.replace(".", "_"),
-                                                      os.path.join(ref_live.REF_ROOT, "utils", "models", "q_resnet.py"))
+        spec = importlib.util.spec_from_file_location("utils.models._" + fname[:-3] + "_over_" + modules_pkg.__name__.replace(".", "_"),
+                                                      os.path.join(ref_live.REF_ROOT, "utils", "models", fname))
         mod = importlib.util.module_from_spec(spec)
         mod.__package__ = "utils.models"
         spec.loader.exec_module(mod)
@@ -99,3 +99,25 @@ def test_the_references_own_graph_runs_over_the_drop_in_modules(arch, cls):
     # (nn.Module.load_state_dict cannot address the dotted child names "stage1.unit1" that the reference registers with setattr -
     # neither its classes nor this mirror strict-load through torch; checkpoints go through hawq_amd.api.load_checkpoint /
     # load_quantized_checkpoint, pinned to files the live reference writes in tests/test_checkpoint.py)
+
+
+def test_mobilenetv2_builder_mirrors_the_references_graph():
+    """hawq_amd.q_mobilenetv2 walks the float network instead of spelling the graph out (it is not a transcription of
+    q_mobilenetv2.py); what it builds must still be the reference's network: same quantized leaves under the same names in the
+    same registration order (= named_modules order the fixtures and bit schedules rely on), same state_dict keys and shapes,
+    same residual / expansion decisions per unit."""
+    from hawq_amd import quant_modules as ours
+    from hawq_amd.q_mobilenetv2 import q_mobilenetv2_w1
+    from hawq_amd.skeleton import build_float_mobilenetv2, init_synthetic
+
+    def skeleton():
+        return init_synthetic(build_float_mobilenetv2(), 0)
+
+    ref_graph = _reference_graph_over(ours, "q_mobilenetv2.py").q_mobilenetv2_w1(skeleton())
+    native = q_mobilenetv2_w1(skeleton())
+    leaves = lambda m: [(n, type(x).__name__) for n, x in m.named_modules() if type(x).__name__.startswith("Quant")]
+    assert leaves(native) == leaves(ref_graph) and len(leaves(native)) == 3 + 17 * 7 + 6
+    assert [(k, tuple(v.shape)) for k, v in native.state_dict().items()] == [(k, tuple(v.shape)) for k, v in ref_graph.state_dict().items()]
+    ref_units = [u for st in ref_graph.features.children() if isinstance(st, type(ref_graph.features)) for u in st.children()]
+    assert [u.residual for u in native.units()] == [u.residual for u in ref_units] and len(ref_units) == 17
+    assert native.channels == ref_graph.channels

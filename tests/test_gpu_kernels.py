@@ -687,6 +687,35 @@ def test_quantconv2d_grouped_depthwise_and_percentile_match_reference_kats():
             assert torch.equal(_rec(y.cpu(), g("s_a"), g("s_w")), _rec(g("y"), g("s_a"), g("s_w"))), tag
 
 
+@pytest.mark.parametrize("shape", [(2, 9, 7, 32, 1), (1, 14, 14, 96, 2), (3, 5, 6, 8, 2), (2, 56, 56, 144, 1), (1, 113, 57, 24, 2), (2, 3, 3, 4, 1)])
+def test_depthwise3x3_matches_the_grouped_kernel_and_numpy(lib, shape):
+    """hawq_depthwise3x3 (4 channels x 4 pixels per thread, tap-major weights; MobileNetV2's conv2) against the plain
+    one-thread-per-output hawq_conv2d_grouped and, for the small cases, a numpy convolution: exact int32 accumulators, odd
+    widths / heights, both strides, with and without bias."""
+    n, h, w, c, stride = shape
+    rng = np.random.default_rng(c * 131 + h)
+    x = rng.integers(-128, 128, (n, h, w, c)).astype(np.int8)
+    wt = rng.integers(-127, 128, (c, 3, 3)).astype(np.int8)
+    b = rng.integers(-30000, 30000, c).astype(np.int32)
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    xd, wg, w9, bd = dev(x), dev(np.ascontiguousarray(wt.reshape(c, 3, 3, 1))), dev(np.ascontiguousarray(wt.reshape(c, 9).T)), dev(b)
+    for bias in (bd, None):
+        out_g = torch.zeros(n * ho * wo * c, dtype=torch.int32, device='cuda')
+        out_d = torch.zeros_like(out_g)
+        bp = bias.data_ptr() if bias is not None else None
+        lib.call("hawq_conv2d_grouped", xd.data_ptr(), wg.data_ptr(), bp, n, h, w, c, c, 3, 3, stride, 1, c, out_g.data_ptr(), stream())
+        lib.call("hawq_depthwise3x3", xd.data_ptr(), w9.data_ptr(), bp, n, h, w, c, stride, out_d.data_ptr(), stream())
+        assert torch.equal(out_d, out_g), shape
+    if n * h * w * c < 50000:
+        xp = np.pad(x.astype(np.int64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+        ref = np.zeros((n, ho, wo, c), np.int64)
+        for kh in range(3):
+            for kw in range(3):
+                ref += xp[:, kh:kh + (ho - 1) * stride + 1:stride, kw:kw + (wo - 1) * stride + 1:stride, :] * wt[:, kh, kw].astype(np.int64)
+        assert np.array_equal(out_d.cpu().numpy().reshape(n, ho, wo, c), ref)
+    assert lib.load().hawq_depthwise3x3(xd.data_ptr(), w9.data_ptr(), None, n, h, w, c + 1, stride, out_d.data_ptr(), None) != 0
+
+
 def test_range_statistics_kernels_match_reference_kats(lib):
     """hawq_minmax_f32 / hawq_kthvalue_f32 behind get_percentile_min_max and the un-frozen QuantAct (min/max and
     percentile ranges, initialisation + momentum / running-extremum updates) against the live reference's numbers."""

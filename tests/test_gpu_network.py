@@ -194,8 +194,8 @@ def test_concurrent_sub_batches_are_bit_identical():
             # the joint tuning pass leaves every chain with the same tile / fused-variant choice per layer
             for sub in eng.subs[1:]:
                 assert [a.tile for a in sub._conv_args] == [a.tile for a in eng.subs[0]._conv_args]
-                assert [(p.fused, p.er.tile if p.fused else (p.expand.tile, p.reduce.tile)) for p in sub._er_args] == \
-                       [(p.fused, p.er.tile if p.fused else (p.expand.tile, p.reduce.tile)) for p in eng.subs[0]._er_args] or \
+                choice = lambda p: (p.fused, p.er.tile if p.fused else (p.expand.tile, p.reduce.tile if p.reduce is not None else 0))
+                assert [choice(p) for p in sub._er_args] == [choice(p) for p in eng.subs[0]._er_args] or \
                        all(p.fused == q.fused for p, q in zip(sub._er_args, eng.subs[0]._er_args))
         assert not eng.overflowed()
     os.environ["HAWQ_JOINT_TUNE"] = "0"   # isolated timing only: another plan, the same logits

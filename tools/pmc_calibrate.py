@@ -36,7 +36,9 @@ def run():
 
 def report(db):
     c = sqlite3.connect(db)
-    rows = c.execute("select kernel_name, grid_size, counter_name, value, duration from counters_collection order by rowid").fetchall()
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    order = next((k for k in ("dispatch_id", "start", "id") if k in cols), None)   # counters_collection is a view: no rowid
+    rows = c.execute("select kernel_name, grid_size, counter_name, value, duration from counters_collection" + (f" order by {order}" if order else "")).fetchall()
     print("| # | kernel | grid (threads) | counter | KB counted | us |")
     print("|---|---|---|---|---|---|")
     for i, (k, g, cn, v, d) in enumerate(rows):
