@@ -433,6 +433,7 @@ def main():
                        "image": 224, "parallelism": f"dp{world}", "weights": "synthetic seed 0, ranges calibrated on 8 images",
                        "residual_uint16_overflow": overflow,
                        "fast_contract_conv_launches": f"{eng.n_fast}/{eng.n_conv}", "exact_tie_requant_launches": eng.n_tie,
+                       "per_channel_k0_launches": getattr(eng, "n_ck0", None),
                        "autotuned_tiles": plan["tiles"],
                        # candidate expand->reduce pairs: variant id of the fused launch, 0 = two separate launches were faster
                        "fused_expand_reduce_launches": len(fused_pairs), "fused_variants": plan["fused_variants"],

@@ -91,18 +91,24 @@ __device__ __forceinline__ void dma16(const char *src, char *dst) {
 __device__ __forceinline__ void dma4(const char *src, char *dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
 }
+// K0: the host guarantees k == 0 for every channel of this table (hawq_conv_args.fast_tables bit 3): the entry's second word IS the
+// shift, two extraction instructions and the pre-shift disappear (3 of ~17 VALU instructions per residual output; the stage-1/2
+// launches of this kernel are 40-60 % VALU-busy, profiles/r02_e_pmc_MFMA.md)
+template <bool K0 = false>
 __device__ __forceinline__ DyNt ctab_entry(const char *ctab, int ch) {
     const v4i t = *reinterpret_cast<const v4i *>(ctab + ch * 16);
     DyNt d;
-    d.m = t.x, d.s = t.y & 0xff, d.k = t.y >> 8;
+    d.m = t.x, d.s = K0 ? t.y : (t.y & 0xff), d.k = K0 ? 0 : (t.y >> 8);
     d.add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
     return d;
 }
 
-template <class F, bool TIE>
+template <class F, bool TIE, bool CK0 = false>
 __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MODE = TIE ? 2 : 0;
+    constexpr int MODE = TIE ? 2 : 0;                    // scalar tables (identity pass-through, next QuantAct)
+    constexpr int MODE_C = TIE ? 2 : (CK0 ? 1 : 0);      // per-channel tables
+    constexpr bool K0 = CK0 && !TIE;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool producer = F::NP > 0 && wave >= F::NW;
     const int m0 = blockIdx.x * F::BM;
@@ -286,9 +292,9 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 int o[4], qv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const DyNt dm = ctab_entry(ctb, lch + 4 * g + k);
-                    const int a = dyadic_mode<MODE>(acc1[4 * g + k], dm);
-                    const int b = F::DUAL ? dyadic_mode<MODE>(acc_id[4 * g + k], ctab_entry(ctb + 2048, lch + 4 * g + k))
+                    const DyNt dm = ctab_entry<K0>(ctb, lch + 4 * g + k);
+                    const int a = dyadic_mode<MODE_C>(acc1[4 * g + k], dm);
+                    const int b = F::DUAL ? dyadic_mode<MODE_C>(acc_id[4 * g + k], ctab_entry<K0>(ctb + 2048, lch + 4 * g + k))
                                           : dyadic_mode<MODE>(idin[k], dids);
                     o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
                     qv[k] = min(dyadic_mode<MODE>(o[k], dq), p.q_hi);      // o >= 0, m >= 0: q >= 0
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                 int qv[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    qv[k] = med3i(dyadic_mode<MODE>(acc2[c][4 * g + k], ctab_entry((const char *)p.ctab1, ch0 + 4 * g + k)), p.y_lo, p.y_hi);
+                    qv[k] = med3i(dyadic_mode<MODE_C>(acc2[c][4 * g + k], ctab_entry<K0>((const char *)p.ctab1, ch0 + 4 * g + k)), p.y_lo, p.y_hi);
                 w[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
             }
             const v4i ww = {w[0], w[1], w[2], w[3]};
@@ -400,8 +406,8 @@ using E64D = ERCfg<64, 2, 0, false, 4, true>;   // stage 1, first unit: identity
 constexpr int NUM_ER = 10;
 
 typedef void (*ERFn)(const ERP);
-struct ERInfo { ERFn fn[2]; int c, bm, nt, lds; bool dual; };
-#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::DUAL}
+struct ERInfo { ERFn fn[3]; int c, bm, nt, lds; bool dual; };   // fn: {general, exact-tie, all per-channel pre-shifts zero}
+#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>, expand_reduce_kernel<F, false, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::DUAL}
 const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P), ER_ENTRY(E256S), ER_ENTRY(E256SP), ER_ENTRY(E64D)};
 
 bool conv_is_1x1_int8_fast(const hawq_conv_args &a, bool dual_ok = false) {
@@ -490,13 +496,13 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     static const bool attrs = [] {
         bool good = true;
         for (const ERInfo &k : kER)
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 3; ++i)
                 good &= hipFuncSetAttribute((const void *)k.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, k.lds) == hipSuccess;
         return good;
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv_expand_reduce: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    const bool tie = ((e.fast_tables | r.fast_tables) & 4) != 0;
-    hipLaunchKernelGGL(ei.fn[tie ? 1 : 0], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
+    const bool tie = ((e.fast_tables | r.fast_tables) & 4) != 0, ck0 = (e.fast_tables & 8) && (r.fast_tables & 8);
+    hipLaunchKernelGGL(ei.fn[tie ? 1 : (ck0 ? 2 : 0)], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {  // experiment hook (synchronises!)
         long long hb[8];

@@ -494,6 +494,7 @@ class IntegerEngine:
                 self._autotune_joint()
             self.n_fast, self.n_conv, self.n_k0, self.n_tie = (self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0,
                                                               self.subs[0].n_tie)
+            self.n_ck0 = self.subs[0].n_ck0
             self.tile_choice, self.er_choice = self.subs[0].tile_choice, self.subs[0].er_choice
             self.er_split_tiles = getattr(self.subs[0], "er_split_tiles", {})
             return
@@ -502,7 +503,7 @@ class IntegerEngine:
         self._conv_args, self._conv_names = [], []
         self.acc_taps = {}
         self.res_taps = {}   # unit name -> (stored post-ReLU residual tensor of this plan, NHWC shape): parity tests read them back
-        self.n_fast = self.n_conv = self.n_k0 = self.n_tie = 0  # how many conv launches run the fast-contract kernels (/ shift-free)
+        self.n_fast = self.n_conv = self.n_k0 = self.n_tie = self.n_ck0 = 0  # how many conv launches run the fast-contract kernels (/ shift-free)
         sp = self.stream.cuda_stream
         ptr = lambda t: None if t is None else t.data_ptr()
         rdt = torch.uint16 if self.res_bits == 16 else torch.int32
@@ -576,6 +577,7 @@ class IntegerEngine:
                 self.n_k0 += int(a.fast_tables == 3)
                 if a.fast_tables and ent.get('ck0', False):
                     a.fast_tables |= 8  # every per-channel pre-shift of this launch's ctab (and ctab_id) is zero
+                    self.n_ck0 += 1
                 if a.fast_tables:
                     a.ctab = ent['ctab'].data_ptr()
                     if ci == len(u['convs']) - 1 and u['resize']:

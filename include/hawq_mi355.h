@@ -110,7 +110,11 @@ typedef struct hawq_conv_args {
                              (mq, eq) is 0 (checked for eq; currently not used to pick a kernel).
                              Bit 2 (value 5): the tie-freedom proof FAILED for some entry; the kernel
                              then applies the exact round-half-even tie correction to every requant
-                             of the call (e in [33,62] and |value << k| < 2^31 still required).     */
+                             of the call (e in [33,62] and |value << k| < 2^31 still required).
+                             Bit 3 (value | 8): every PER-CHANNEL pre-shift k of this conv's ctab (and ctab_id) is 0
+                             (the scalar tables may still carry one): hawq_conv_expand_reduce then runs the
+                             instantiation without the shift / field extraction (3 VALU instructions per output
+                             fewer); other entry points ignore the bit.                                          */
     int32_t in_planar;    /* layout of `in`: 0 = NHWC pixel rows [M][Cin*bits/8];  1 = channel-group planes
                              [Cin/G][M][16 B] with G = 16 (int8) / 32 (hawq4) channels per 16-byte unit.  Planes
                              are what the 3x3 band kernels' LDS-DMA fill wants (64 consecutive pixels of one plane
