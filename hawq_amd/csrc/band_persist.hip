@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -29,6 +31,7 @@ struct BPP {
     float rcp_wo, rcp_ho;
     int q_lo, q_hi;
     int ntiles;
+    int ck0;         // every per-channel pre-shift of ctab is zero (hawq_conv_args.fast_tables bit 3): the shorter requant
     long long *dbgbuf;
 };
 
@@ -196,25 +199,32 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
         __builtin_amdgcn_s_barrier();   // B(tile): the band may be refilled
         // ------------------------------------------------------------------ epilogue: requant, private transposition, 64-byte rows
         int w[2][2][4];   // [pixel tile][channel tile][4 channels each]
+        // the kernel is bound by the ISSUE of this requantisation (profiles/r02_band_persist.md): with all pre-shifts zero (the
+        // usual case, a wave-uniform flag) the table word IS the shift amount - no field extraction, no pre-shift: 3.75 instead
+        // of 5.75 VALU instructions per output.  Uniform branch between two instantiations of the same code
+        auto requant_all = [&](auto K0c) {
+            constexpr bool K0 = decltype(K0c)::value;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                DyNt dm[4];
+                for (int g = 0; g < 4; ++g) {
+                    DyNt dm[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const v4i e = *reinterpret_cast<const v4i *>(ctb + (c * 32 + h * 16 + 4 * g + j) * 16);
-                    dm[j].m = e.x, dm[j].s = e.y & 0xff, dm[j].k = e.y >> 8;
-                    dm[j].add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
+                    for (int j = 0; j < 4; ++j) {
+                        const v4i e = *reinterpret_cast<const v4i *>(ctb + (c * 32 + h * 16 + 4 * g + j) * 16);
+                        dm[j].m = e.x, dm[j].s = K0 ? e.y : (e.y & 31), dm[j].k = K0 ? 0 : (e.y >> 8);
+                        dm[j].add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        int qv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) qv[j] = med3i(dyadic_mode<(K0 && MODE == 0) ? 1 : MODE>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
+                        w[q][c][g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                    }
                 }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    int qv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) qv[j] = med3i(dyadic_mode<MODE>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
-                    w[q][c][g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
-                }
-            }
+        };
+        requant_all(std::false_type{});   // (the all-k-zero form under a wave-uniform branch measured neutral in the forward: not kept)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -258,6 +268,7 @@ int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs
     p.rcp_wo = 1.0f / (float)a->W, p.rcp_ho = 1.0f / (float)a->H;
     p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
     p.ntiles = (p.M + BM - 1) / BM;
+    p.ck0 = (a->fast_tables & 8) != 0;
     static long long *dbg_dev = nullptr;
     if (HAWQ_DBG_BIT(dbg, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 8 * sizeof(long long));
     p.dbgbuf = HAWQ_DBG_BIT(dbg, 128) ? dbg_dev : nullptr;

@@ -68,6 +68,8 @@ __device__ __forceinline__ int32_t dyadic_rne(int32_t v, int32_t m, int32_t ek) 
 // Then round-half-even == round-half-up == floor((v*m + 2^(e-1)) / 2^e), the bias 2^(e-1) lives
 // entirely in the high word and can be the 64-bit addend of ONE v_mad_i64_i32, and the quotient is
 // an arithmetic shift of the high word:  2 VALU instructions.
+// (callers extract s from a table word with `& 31`, not `& 0xff`: s = e - 32 is in [1, 30], and a 5-bit mask folds into the shift
+// instruction - the hardware ignores the upper bits of a shift amount - while `& 0xff` is a VALU instruction per output)
 struct DyNt {
     int m, s, k;
     long long add;  // 2^(e-1) = (1 << (s-1)) << 32   (+ (bias << k) * m when the bias is folded in)
@@ -145,6 +147,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ int pack4_fast(int a, int b, int c, int d) {
     typedef short s2 __attribute__((ext_vector_type(2)));
     const s2 lo = __builtin_amdgcn_cvt_pk_i16(a, b), hi = __builtin_amdgcn_cvt_pk_i16(c, d);
+    return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
+}
+// 4 NON-NEGATIVE ints -> min(., hi) -> one dword of bytes: the upper clamp runs on the packed int16 pairs (v_pk_min_i16: one
+// instruction per two values; v_cvt_pk_i16_i32 saturates at 32767 >= hi, so min(sat16(x), hi) == min(x, hi) for x >= 0, 0 <= hi <= 32767)
+__device__ __forceinline__ int pack4_min(int a, int b, int c, int d, int hi2 /* hi | hi << 16 */) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const s2 h2 = __builtin_bit_cast(s2, hi2);
+    const s2 lo = __builtin_elementwise_min(__builtin_amdgcn_cvt_pk_i16(a, b), h2), hi = __builtin_elementwise_min(__builtin_amdgcn_cvt_pk_i16(c, d), h2);
     return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x06040200u);
 }
 // two non-negative ints -> saturating uint16 pair (v_cvt_pk_u16_u32)

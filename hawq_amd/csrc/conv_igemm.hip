@@ -46,6 +46,7 @@ struct ConvP {
     int32_t *flags;
     const int32_t *ctab, *ctab_id;
     int k0;   // fast path requant mode (dyadic_mode): 0 tie-free, 1 tie-free + every pre-shift 0, 2 exact tie handling
+    int ck0;  // every PER-CHANNEL pre-shift (ctab, ctab_id) is zero (fast_tables bit 3): epilogue_fast<..., CK0 = true>
     int ring_bytes;  // LDS bytes of the operand ring actually allocated (fewer stages when the K loop is shorter than the ring)
     int in_planar, out_planar;  // activation layout of in / out_q: 0 = NHWC rows, 1 = channel-group planes (hawq_mi355.h)
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
@@ -596,7 +597,11 @@ __device__ __forceinline__ void prefetch_residual(const ConvP &p, int m0, int c0
 // MODE: see dyadic_mode (0 = tie-free tables, 2 = exact tie handling for every table; 1 = tie-free and shift-free is
 // implemented but not instantiated: as a run-time variant it cost registers (spills in the 64x64 dual kernels) for
 // a gain inside the measurement noise)
-template <class C, int EPI, bool DUAL, int MODE = 0>
+// CK0: the per-channel tables carry no pre-shift: the table word is the shift amount itself (3 VALU instructions per requantised
+// accumulator fewer).  NOT instantiated: a wave-uniform branch between the two forms in every fast kernel measured neutral in the
+// forward (same-plan A/B 93.08 vs 93.04 k img/s, profiles/r03_valu_trims.md) - these epilogues are not VALU-bound; the fused
+// expand -> reduce kernels (fused_er.hip / fused_wp.hip), which are, have their own all-k-zero instantiations
+template <class C, int EPI, bool DUAL, int MODE = 0, bool CK0 = false>
 __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT][C::PT],
                                               v16i (&acc2)[DUAL ? C::CT : 1][DUAL ? C::PT : 1], int m0, int c0,
                                               char *q_tile, char *res_tile, const char *ctab_lds,
@@ -604,12 +609,15 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
     // active == false: a wave that owns no accumulators (band-kernel producer); it only helps with the stores
     using S = Stage<C>;
     constexpr bool RES = EPI == HAWQ_EPI_RESIDUAL;
-    constexpr bool K0 = MODE == 1;
+    constexpr bool K0 = MODE == 1 || CK0;                      // per-channel tables
+    constexpr int MODE_C = (CK0 && MODE == 0) ? 1 : MODE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_m = wave % C::WM, wave_c = (wave / C::WM) % C::WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int lrow0 = wave_m * (C::PT * 32) + l31;  // tile-local pixel row of pixel tile 0
-    const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    asm volatile("" : "+s"(dids.add), "+s"(dq.add));   // opaque rounding constants: one v_mad_i64_i32 instead of v_mul_hi_i32 + v_add (see fused_er.hip)
+    const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);   // RESIDUAL: q >= 0, clamped from above as packed int16 pairs
     unsigned oor = 0;               // OR of all residual outputs: bits >= 16 set <=> uint16 overflow
     unsigned rowmask[C::PT];
 #pragma unroll
@@ -642,11 +650,11 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const v4i t = *reinterpret_cast<const v4i *>(ctab_lds + (lch + 4 * g + j) * 16);
-                dm[j].m = t.x, dm[j].s = K0 ? t.y : (t.y & 0xff), dm[j].k = K0 ? 0 : (t.y >> 8);
+                dm[j].m = t.x, dm[j].s = K0 ? t.y : (t.y & 31), dm[j].k = K0 ? 0 : (t.y >> 8);
                 dm[j].add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
                 if constexpr (DUAL) {
                     const v4i u = *reinterpret_cast<const v4i *>(ctab_lds + C::BN * 16 + (lch + 4 * g + j) * 16);
-                    di[j].m = u.x, di[j].s = K0 ? u.y : (u.y & 0xff), di[j].k = K0 ? 0 : (u.y >> 8);
+                    di[j].m = u.x, di[j].s = K0 ? u.y : (u.y & 31), di[j].k = K0 ? 0 : (u.y >> 8);
                     di[j].add = (long long)(((unsigned long long)(unsigned)u.w << 32) | (unsigned)u.z);
                 } else {
                     di[j] = dids;
@@ -660,7 +668,7 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     // ReLU commutes with the (monotone, 0 -> 0) requantisation: it is folded into q_lo
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        qv[j] = med3i(dyadic_mode<MODE>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
+                        qv[j] = med3i(dyadic_mode<MODE_C>(acc[c][q][4 * g + j], dm[j]), p.q_lo, p.q_hi);
                 } else {
                     int idin[4], o[4];
                     if constexpr (DUAL) {
@@ -673,17 +681,17 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int a = dyadic_mode<MODE>(acc[c][q][4 * g + j], dm[j]);
-                        const int b = DUAL ? dyadic_mode<MODE>(idin[j], di[j]) : dyadic_mode<MODE == 2 ? 2 : 0>(idin[j], di[j]);
+                        const int a = dyadic_mode<MODE_C>(acc[c][q][4 * g + j], dm[j]);
+                        const int b = DUAL ? dyadic_mode<MODE_C>(idin[j], di[j]) : dyadic_mode<MODE == 2 ? 2 : 0>(idin[j], di[j]);
                         o[j] = max(a + b, 0);  // no clamp: quant_utils.py:456
-                        qv[j] = min(dyadic_mode<MODE>(o[j], dq), p.q_hi);  // o >= 0 and m >= 0: q >= 0 >= q_lo
+                        qv[j] = dyadic_mode<MODE>(o[j], dq);  // o >= 0 and m >= 0: q >= 0 >= q_lo; the upper clamp runs on the packed pairs
                     }
                     // rows beyond M hold bias-only garbage: they never reach memory and must not raise the flag
                     oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask[q];
                     rpack[qq][RES ? 2 * g : 0] = pack2_u16_sat(o[0], o[1]);
                     rpack[qq][RES ? 2 * g + 1 : 0] = pack2_u16_sat(o[2], o[3]);
                 }
-                const int w = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                const int w = RES ? pack4_min(qv[0], qv[1], qv[2], qv[3], qhi2) : pack4_fast(qv[0], qv[1], qv[2], qv[3]);
                 if (p.out_bits == 8) {
                     qpack[qq][g] = w;
                 } else if (g & 1) {  // hawq4: low nibbles = channels 0-3 of the 8-group, high = 4-7
@@ -1422,6 +1430,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (HAWQ_DBG_BIT(p.dbg, 128)) p.dbgbuf = dbg_dev;
     const bool fast = a->fast_tables != 0;
     p.k0 = (a->fast_tables & 4) ? 2 : ((a->fast_tables & 2) ? 1 : 0);
+    p.ck0 = (a->fast_tables & 8) != 0;
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
         if (a->epilogue == HAWQ_EPI_REQUANT && a->relu && p.q_lo < 0) p.q_lo = 0;  // ReLU folded into the clamp
@@ -1434,6 +1443,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         if (a->out_q) {
             HAWQ_REQUIRE(a->mq >= 0 && e_any(a->eq), "hawq_conv2d: bad (mq, eq)");
             HAWQ_REQUIRE(!fast || e_fast(a->eq), "hawq_conv2d: fast_tables needs eq in [33,62]");
+            HAWQ_REQUIRE(!fast || (a->q_hi >= 0 && a->q_hi <= 32767), "hawq_conv2d: fast_tables needs 0 <= q_hi <= 32767 for the next QuantAct");
             HAWQ_REQUIRE(p.k0 != 1 || (a->eq >> 8) == 0, "hawq_conv2d: fast_tables bit 1 (no pre-shifts) but eq carries one");
         } else {
             p.mq = 0, p.eq = 33;

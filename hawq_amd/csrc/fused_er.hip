@@ -98,15 +98,17 @@ template <bool K0 = false>
 __device__ __forceinline__ DyNt ctab_entry(const char *ctab, int ch) {
     const v4i t = *reinterpret_cast<const v4i *>(ctab + ch * 16);
     DyNt d;
-    d.m = t.x, d.s = K0 ? t.y : (t.y & 0xff), d.k = K0 ? 0 : (t.y >> 8);
+    d.m = t.x, d.s = K0 ? t.y : (t.y & 31), d.k = K0 ? 0 : (t.y >> 8);
     d.add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
     return d;
 }
 
-template <class F, bool TIE, bool CK0 = false>
+// QK0: the next unit's QuantAct table (mq, eq) carries no pre-shift either (the usual case: a 16-bit -> 8-bit ratio is ~2^-7)
+template <class F, bool TIE, bool CK0 = false, bool QK0 = false>
 __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MODE = TIE ? 2 : 0;                    // scalar tables (identity pass-through, next QuantAct)
+    constexpr int MODE = TIE ? 2 : 0;                    // scalar identity table (uniform pre-shift)
+    constexpr int MODE_Q = TIE ? 2 : (QK0 ? 1 : 0);      // scalar table of the next QuantAct
     constexpr int MODE_C = TIE ? 2 : (CK0 ? 1 : 0);      // per-channel tables
     constexpr bool K0 = CK0 && !TIE;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -216,8 +218,13 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
     const int arow = wave_m * 32 + l31;                           // this lane's pixel row (both GEMMs, both epilogues)
     const int wrow1 = wave_c * 32 + cperm(l31);                   // GEMM1: W3 slice row
     const int lch = wave_c * 32 + h * 16;                         // slice-local first channel of this lane's 16 outputs
-    const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    // hide the (zero) low words of the scalar tables' rounding constants from the optimiser: knowing them it splits the 64-bit
+    // multiply-add into v_mul_hi_i32 + v_add; opaque, it emits ONE v_mad_i64_i32 with the constant as an SGPR-pair addend
+    // (2 of ~17 VALU instructions per residual output)
+    asm volatile("" : "+s"(dids.add), "+s"(dq.add));
     const unsigned rowmask = (m0 + arow < p.M) ? 0xffffffffu : 0u;
+    const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);
     const int res_row = (m0 + arow < p.M) ? m0 + arow : m0;       // rows beyond M read a valid row and are never stored
     unsigned oor = 0;
     if constexpr (F::NP == 0) issue_prologue();
@@ -297,12 +304,12 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
                     const int b = F::DUAL ? dyadic_mode<MODE_C>(acc_id[4 * g + k], ctab_entry<K0>(ctb + 2048, lch + 4 * g + k))
                                           : dyadic_mode<MODE>(idin[k], dids);
                     o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
-                    qv[k] = min(dyadic_mode<MODE>(o[k], dq), p.q_hi);      // o >= 0, m >= 0: q >= 0
+                    qv[k] = dyadic_mode<MODE_Q>(o[k], dq);                 // o >= 0, m >= 0: q >= 0; clamped from above in the pack
                 }
                 oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask;
                 rpack[2 * g] = pack2_u16_sat(o[0], o[1]);
                 rpack[2 * g + 1] = pack2_u16_sat(o[2], o[3]);
-                qpack[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                qpack[g] = pack4_min(qv[0], qv[1], qv[2], qv[3], qhi2);
             }
             const v4i ra = {rpack[0], rpack[1], rpack[2], rpack[3]}, rc = {rpack[4], rpack[5], rpack[6], rpack[7]};
             *reinterpret_cast<v4i *>(rb + (((lch >> 3) ^ (arow & 7)) << 4)) = ra;
@@ -406,8 +413,9 @@ using E64D = ERCfg<64, 2, 0, false, 4, true>;   // stage 1, first unit: identity
 constexpr int NUM_ER = 10;
 
 typedef void (*ERFn)(const ERP);
-struct ERInfo { ERFn fn[3]; int c, bm, nt, lds; bool dual; };   // fn: {general, exact-tie, all per-channel pre-shifts zero}
-#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>, expand_reduce_kernel<F, false, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::DUAL}
+struct ERInfo { ERFn fn[5]; int c, bm, nt, lds; bool dual; };   // fn: {general, exact-tie, per-channel k all zero, + next-QuantAct k zero, only the latter}
+#define ER_ENTRY(F) {{expand_reduce_kernel<F, false>, expand_reduce_kernel<F, true>, expand_reduce_kernel<F, false, true>, expand_reduce_kernel<F, false, true, true>, \
+                      expand_reduce_kernel<F, false, false, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::DUAL}
 const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P), ER_ENTRY(E256S), ER_ENTRY(E256SP), ER_ENTRY(E64D)};
 
 bool conv_is_1x1_int8_fast(const hawq_conv_args &a, bool dual_ok = false) {
@@ -496,13 +504,15 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     static const bool attrs = [] {
         bool good = true;
         for (const ERInfo &k : kER)
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 5; ++i)
                 good &= hipFuncSetAttribute((const void *)k.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, k.lds) == hipSuccess;
         return good;
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv_expand_reduce: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     const bool tie = ((e.fast_tables | r.fast_tables) & 4) != 0, ck0 = (e.fast_tables & 8) && (r.fast_tables & 8);
-    hipLaunchKernelGGL(ei.fn[tie ? 1 : (ck0 ? 2 : 0)], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
+    const bool qk0 = (e.eq >> 8) == 0;
+    HAWQ_REQUIRE(e.q_hi >= 0 && e.q_hi <= 32767, "hawq_conv_expand_reduce: q_hi outside [0, 32767]");
+    hipLaunchKernelGGL(ei.fn[tie ? 1 : (ck0 ? (qk0 ? 3 : 2) : (qk0 ? 4 : 0))], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {  // experiment hook (synchronises!)
         long long hb[8];

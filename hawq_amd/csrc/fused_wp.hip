@@ -66,7 +66,7 @@ template <bool K0>
 __device__ __forceinline__ DyNt wp_ctab(const char *ctab, int ch) {
     const v4i t = *reinterpret_cast<const v4i *>(ctab + ch * 16);
     DyNt d;
-    d.m = t.x, d.s = K0 ? t.y : (t.y & 0xff), d.k = K0 ? 0 : (t.y >> 8);
+    d.m = t.x, d.s = K0 ? t.y : (t.y & 31), d.k = K0 ? 0 : (t.y >> 8);
     d.add = (long long)(((unsigned long long)(unsigned)t.w << 32) | (unsigned)t.z);
     return d;
 }
@@ -93,10 +93,11 @@ struct WPCfg {
     static_assert(RPP % 16 == 0 && (NW == 1 || NW == 2 || NW % 4 == 0), "producer passes must cover whole swizzle groups");
 };
 
-template <class F, bool TIE, bool CK0>
+template <class F, bool TIE, bool CK0, bool QK0 = false>
 __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MODE_S = TIE ? 2 : 0;                  // scalar tables (identity pass-through, next QuantAct): uniform pre-shift
+    constexpr int MODE_S = TIE ? 2 : 0;                  // scalar identity table: uniform pre-shift
+    constexpr int MODE_Q = TIE ? 2 : (QK0 ? 1 : 0);      // scalar table of the next QuantAct (QK0: no pre-shift)
     constexpr int MODE_C = TIE ? 2 : (CK0 ? 1 : 0);      // per-channel tables
     constexpr bool K0 = CK0 && !TIE;
     constexpr int C = F::C;
@@ -182,8 +183,10 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
     }
-    const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+    asm volatile("" : "+s"(dids.add), "+s"(dq.add));   // opaque rounding constants: one v_mad_i64_i32 instead of v_mul_hi_i32 + v_add (see fused_er.hip)
     const unsigned rowmask = valid ? 0xffffffffu : 0u;
+    const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);
     unsigned oor = 0;
     const int cp = cperm(l31);
     const unsigned a0 = lds_addr(smem) + lds_off(cp, h), a1 = lds_addr(smem) + lds_off(cp, 2 + h);   // K-steps 0 / 1 of a 64-byte row
@@ -260,12 +263,12 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
                         const int a = dyadic_mode<MODE_C>(acc1[tl][4 * g + k], dm);
                         const int b = dyadic_mode<MODE_S>(idin[k], dids);
                         o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
-                        qv[k] = min(dyadic_mode<MODE_S>(o[k], dq), p.q_hi);    // o >= 0, m >= 0: q >= 0
+                        qv[k] = dyadic_mode<MODE_Q>(o[k], dq);                 // o >= 0, m >= 0: q >= 0; clamped from above in the pack
                     }
                     oor |= ((unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3])) & rowmask;
                     rout[2 * tl + (g >> 1)][(g & 1) * 2] = pack2_u16_sat(o[0], o[1]);
                     rout[2 * tl + (g >> 1)][(g & 1) * 2 + 1] = pack2_u16_sat(o[2], o[3]);
-                    qp[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                    qp[g] = pack4_min(qv[0], qv[1], qv[2], qv[3], qhi2);
                 }
                 qf[tl] = v4i{qp[0], qp[1], qp[2], qp[3]};
             }
@@ -356,8 +359,9 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
 
 // ---- variant table ------------------------------------------------------------------------------------------------
 typedef void (*WPFn)(const WPP);
-struct WPInfo { WPFn fn[3]; int c, bm, nt, lds; bool reduce; int ysplit; };
-#define WP_ENTRY(F, YS) {{expand_wp_kernel<F, false, false>, expand_wp_kernel<F, false, true>, expand_wp_kernel<F, true, false>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::REDUCE, YS}
+struct WPInfo { WPFn fn[5]; int c, bm, nt, lds; bool reduce; int ysplit; };   // fn: {general, per-channel k zero, exact-tie, ck0 + next-QuantAct k zero, only the latter}
+#define WP_ENTRY(F, YS) {{expand_wp_kernel<F, false, false>, expand_wp_kernel<F, false, true>, expand_wp_kernel<F, true, false>, expand_wp_kernel<F, false, true, true>, \
+                          expand_wp_kernel<F, false, false, true>}, F::C, F::BM, F::NT, F::LDS_BYTES, F::REDUCE, YS}
 using W64 = WPCfg<64, 4, true, 3>;       // stage 1: 128 pixels, 18 KiB of LDS
 using W64B = WPCfg<64, 8, true, 3>;      //          256 pixels: half the weight traffic per pixel
 using W128 = WPCfg<128, 4, true, 2>;     // stage 2: 34 KiB
@@ -437,7 +441,7 @@ int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     static const bool attrs = [] {
         bool good = true;
         for (const WPInfo &k : kWP)
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 5; ++i)
                 good &= hipFuncSetAttribute((const void *)k.fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, k.lds) == hipSuccess;
         return good;
     }();
@@ -445,7 +449,9 @@ int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     const int ft = e.fast_tables | (wi.reduce ? r.fast_tables : 0);
     // bit 2: some table is not provably tie-free; bit 3 (on BOTH convs): every per-channel pre-shift is zero
     const bool tie = (ft & 4) != 0, ck0 = (e.fast_tables & 8) && (!wi.reduce || (r.fast_tables & 8));
-    hipLaunchKernelGGL(wi.fn[tie ? 2 : (ck0 ? 1 : 0)], dim3((p.M + wi.bm - 1) / wi.bm, wi.ysplit), dim3(wi.nt), wi.lds, (hipStream_t)stream, p);
+    const bool qk0 = (e.eq >> 8) == 0;
+    HAWQ_REQUIRE(e.q_hi >= 0 && e.q_hi <= 32767, "hawq_conv_expand_reduce: q_hi outside [0, 32767]");
+    hipLaunchKernelGGL(wi.fn[tie ? 2 : (ck0 ? (qk0 ? 3 : 1) : (qk0 ? 4 : 0))], dim3((p.M + wi.bm - 1) / wi.bm, wi.ysplit), dim3(wi.nt), wi.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {   // probe builds only (synchronises!)
         long long hb[8];

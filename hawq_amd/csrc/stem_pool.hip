@@ -347,8 +347,15 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
                 const v4i af = *reinterpret_cast<const v4i *>(wbase + ((2 * dy + kh) * SF_PW) * 4);
                 acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[kh], af, acc0, 0, 0, 0);
             }
+            // window positions that can fall outside the conv map (max-pool padding = -inf): the top row / left column, and - for
+            // odd conv sizes only - the bottom row / right column of the last pooled pixel
+            if (dy == 0 || dx == 0 || (((Hc | Wc) & 1) && (dy == 2 || dx == 2))) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) best[r] = max(best[r], cvalid ? acc0[r] : (int)0x80000000);
+                for (int r = 0; r < 16; ++r) best[r] = max(best[r], cvalid ? acc0[r] : (int)0x80000000);
+            } else {   // 4 of the 9 positions (ImageNet's even 112 x 112 map) are inside for every pooled pixel: no select
+#pragma unroll
+                for (int r = 0; r < 16; ++r) best[r] = max(best[r], acc0[r]);
+            }
         }
     }
     {

@@ -110,7 +110,7 @@ def conv_args(lib, x, wt, b, stride, pad, a_bits, w_bits, tile=0):
 # (pixels per workgroup, channel tile, band pixels per LDS stage, needs a single 64-channel slice) of the 3x3 band
 # tiles, in tile-id order (the last ids of hawq_conv2d_num_tiles())
 BAND_GEOM = [(256, 64, 512, True), (256, 128, 512, False), (128, 128, 256, False), (256, 128, 384, False),
-             (128, 128, 256, False), (256, 64, 512, True), (256, 64, 512, True)]
+             (128, 128, 256, False), (128, 64, 256, False), (256, 64, 512, True), (256, 64, 512, True)]
 PERSIST = len(BAND_GEOM) - 2   # the last two are the weight-stationary kernel (band_persist.hip; 1 / 2 workgroups per CU): Cin == Cout == 64, int8 in and out, REQUANT, NHWC output
 
 SHAPES = [  # n, h, w, cin, cout, k, stride, pad

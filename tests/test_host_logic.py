@@ -286,6 +286,36 @@ def test_mobilenetv2_graph_and_schedules_line_up():
         assert mods["features.stage4.unit5.conv2"].weight_bit == cfg["features.stage4.unit5.conv2"]
 
 
+def test_resize_restatement_agrees_with_torchs_uint8_antialias_bilinear_within_one_lsb():
+    """oracle/pil_resample.py (the checker of the device Resize stage, written by the builder) against an implementation the builder
+    did NOT write: torch-CPU `F.interpolate(uint8, mode="bilinear", antialias=True)`, PyTorch's port of Pillow-SIMD's resampling
+    (what torchvision's Resize runs on uint8 tensors).  torch quantises its filter weights to fewer fractional bits than
+    Pillow's 22, so the two are not bit-identical by construction (torchvision documents +-1 against PIL); what is pinned here:
+    never more than ONE level apart and equal in > 99.5 % of the elements.
+    Parity with Pillow's own output stays unpinned (Pillow is absent from the image) - stated in DESIGN.md 8."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import pil_resample as P
+    rng = np.random.default_rng(0)
+    total = differ = 0
+    for h, w in ((375, 500), (500, 375), (333, 500), (257, 300), (600, 601), (224, 224), (200, 180)):
+        for kind in ("noise", "smooth"):
+            if kind == "noise":
+                img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+            else:
+                yy, xx = np.mgrid[0:h, 0:w]
+                img = np.stack([127 + 120 * np.sin(xx / 17 + yy / 29), 127 + 120 * np.cos(xx / 23 - yy / 13), xx * 255 / w], -1).astype(np.uint8)
+            oh, ow = (int(256 * h / w), 256) if w <= h else (256, int(256 * w / h))
+            ref = P.resize(img, oh, ow)
+            t = torch.from_numpy(img).permute(2, 0, 1).unsqueeze(0)
+            out = F.interpolate(t, size=(oh, ow), mode="bilinear", antialias=True, align_corners=False)[0].permute(1, 2, 0).numpy()
+            d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+            assert d.max() <= 1, (h, w, kind, int(d.max()))
+            total += d.size
+            differ += int((d > 0).sum())
+    assert differ < 0.005 * total, (differ, total)
+
+
 def test_resize_coefficients_match_the_independent_restatement():
     """hawq_amd.image.bilinear_coeffs (vectorised) vs oracle/pil_resample.py (scalar loops, written separately): bounds and
     22-bit coefficients of Pillow's antialiased bilinear resize for down-, up- and identity scaling; taps sum to 2^22 +- taps."""
