@@ -140,7 +140,11 @@ int hawq_conv2d_band_tile(const hawq_conv_args *args);
  * branch) - or, for expand.Cin == 64, a second branch in2 / wgt2 / ctab_id that is a 1x1 / stride-1 conv over the same pixels with
  * Cin2 == 64 (the first unit of ResNet50's stage 1: its requantised accumulators replace the stored residual) -,
  * reduce.Cin == expand.Cout, reduce.Cout == expand.Cin in {64, 128, 256}, 8-bit outputs.
- * tile: 0 = default kernel variant for the channel count, 1..hawq_conv_expand_reduce_variants() = a specific one. */
+ * tile: 0 = default kernel variant for the channel count, 1..hawq_conv_expand_reduce_variants() = a specific one (the variants of
+ * fused_er.hip first, then the wave-private ones of fused_wp.hip: same results, different organisation of the launch).
+ * reduce.wgt == NULL (round 3): the expand conv ALONE on the wave-private kernel - `expand` exactly as for hawq_conv2d with the
+ * RESIDUAL epilogue (single branch, uint16 residual in, 8-bit out_q, res_out optional; expand.Cin in {64, 128, 256, 512}); some
+ * variants split the output channels over gridDim.y.  0 variants = use hawq_conv2d. */
 typedef struct hawq_expand_reduce_args {
     hawq_conv_args expand;
     hawq_conv_args reduce;
