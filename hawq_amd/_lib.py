@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ("out_acc", vp), ("out_f32", vp), ("fscale", vp), ("ldo", i32), ("n_valid", i32),
         ("flags", vp), ("tile", i32), ("ctab", vp), ("ctab_id", vp), ("fast_tables", i32),
         ("in_planar", i32), ("out_planar", i32),
+        ("res_no_relu", i32), ("res_clamp16", i32),
     ]
 
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "hawq_avgpool_f32": [vp, vp, i32, i32, f32, vp],
     "hawq_conv2d_grouped": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "hawq_depthwise3x3": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "hawq_depthwise3x3_requant": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_resample_u8": [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "hawq_minmax_f32": [vp, i64, vp, vp, vp],
     "hawq_kthvalue_f32": [vp, i64, i64, i32, vp, vp, vp],
@@ -108,7 +110,7 @@ def load():
         fn.restype = C.c_int
     lib.hawq_last_error.restype = C.c_char_p
     lib.hawq_last_error.argtypes = []
-    if lib.hawq_abi_version() != 2:
+    if lib.hawq_abi_version() != 3:
         raise HawqLibraryError("libhawq_mi355.so ABI version mismatch")
     _lib = lib
     return lib

@@ -226,8 +226,12 @@ extern "C" int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const in
 // whole 64..256-byte runs of the NHWC rows.  9 MACs per output: the layer is bound by its own bytes, not a matrix-pipe shape.
 namespace {
 constexpr int DW_PX = 4;
+// REQ: conv2 -> ReLU -> QuantAct fused (exact dyadic_rne per channel table), int8 out; `out` (int32) then optional
+template <bool REQ>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ w9c, const int32_t *__restrict__ bias,
-                                                           int N, int H, int W, int C, int stride, int Ho, int Wo, int32_t *__restrict__ out) {
+                                                           int N, int H, int W, int C, int stride, int Ho, int Wo, int32_t *__restrict__ out,
+                                                           const int32_t *__restrict__ mult, const int32_t *__restrict__ expo, int relu, int q_lo, int q_hi,
+                                                           int8_t *__restrict__ out_q) {
     const int cgs = C >> 2, wq = (Wo + DW_PX - 1) / DW_PX;
     const long long total = (long long)N * Ho * wq * cgs;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -267,10 +271,20 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restr
                 }
             }
         }
+        v4i m4 = {0, 0, 0, 0}, e4 = {0, 0, 0, 0};
+        if constexpr (REQ) m4 = *reinterpret_cast<const v4i *>(mult + 4 * cg), e4 = *reinterpret_cast<const v4i *>(expo + 4 * cg);
 #pragma unroll
         for (int p = 0; p < DW_PX; ++p)
-            if (ox0 + p < Wo)
-                *reinterpret_cast<v4i *>(out + (((size_t)n * Ho + oy) * Wo + ox0 + p) * C + 4 * cg) = v4i{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+            if (ox0 + p < Wo) {
+                const size_t o4 = (((size_t)n * Ho + oy) * Wo + ox0 + p) * C + 4 * cg;
+                if (out) *reinterpret_cast<v4i *>(out + o4) = v4i{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+                if constexpr (REQ) {
+                    int qv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qv[j] = clampi(dyadic_rne(relu ? max(acc[p][j], 0) : acc[p][j], m4[j], e4[j]), q_lo, q_hi);
+                    *reinterpret_cast<uint32_t *>(out_q + o4) = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+                }
+            }
     }
 }
 }  // namespace
@@ -283,7 +297,24 @@ extern "C" int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const in
     HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3: empty output");
     const long long total = (long long)N * Ho * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(depthwise3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, stride, Ho, Wo, out_acc);
+    hipLaunchKernelGGL(depthwise3x3_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, stride, Ho, Wo, out_acc,
+                       nullptr, nullptr, 0, 0, 0, nullptr);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e,
+                                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu, int32_t q_lo, int32_t q_hi,
+                                         int8_t *out_q, int32_t *out_acc, void *stream) {
+    HAWQ_REQUIRE(in && wgt9c && m && e && out_q, "hawq_depthwise3x3_requant: null pointer");
+    HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3_requant: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
+    HAWQ_REQUIRE(q_lo >= -128 && q_hi <= 127 && q_lo <= q_hi, "hawq_depthwise3x3_requant: the clamp must fit int8");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3_requant: empty output");
+    const long long total = (long long)N * Ho * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(depthwise3x3_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, stride, Ho, Wo, out_acc,
+                       m, e, relu, q_lo, q_hi, out_q);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

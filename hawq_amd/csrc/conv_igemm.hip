@@ -47,6 +47,7 @@ struct ConvP {
     const int32_t *ctab, *ctab_id;
     int k0;   // fast path requant mode (dyadic_mode): 0 tie-free, 1 tie-free + every pre-shift 0, 2 exact tie handling
     int ck0;  // every PER-CHANNEL pre-shift (ctab, ctab_id) is zero (fast_tables bit 3): epilogue_fast<..., CK0 = true>
+    int res_no_relu, res_clamp16;   // exact general RESIDUAL epilogue: no ReLU after the sum / clamp to the int16 range (hawq_conv_args)
     int ring_bytes;  // LDS bytes of the operand ring actually allocated (fewer stages when the K loop is shorter than the ring)
     int in_planar, out_planar;  // activation layout of in / out_q: 0 = NHWC rows, 1 = channel-group planes (hawq_mi355.h)
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
@@ -514,17 +515,22 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
                                       e1[4] = {ei.x, ei.y, ei.z, ei.w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) idv[j] = dyadic_rne(acc2[DUAL ? c : 0][DUAL ? q : 0][4 * g + j] + bb2[j], m1[j], e1[j]);
-                        } else {
+                        } else if (p.res_in) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int r = p.res_in_bits == 16 ? (int)((const uint16_t *)p.res_in)[elem + 4 * g + j]
                                                                   : ((const int32_t *)p.res_in)[elem + 4 * g + j];
                                 idv[j] = dyadic_rne(r, p.m_id_s, p.e_id_s);
                             }
+                        } else {   // no identity branch (MobileNetV2 units that change shape): fixedpoint_fn case 0
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) idv[j] = 0;
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            o[j] = max(dyadic_rne(v[j], mm[j], ee[j]) + idv[j], 0);  // no clamp: quant_utils.py:456
+                            o[j] = dyadic_rne(v[j], mm[j], ee[j]) + idv[j];          // no clamp with an identity: quant_utils.py:456
+                            if (!p.res_no_relu) o[j] = max(o[j], 0);
+                            if (p.res_clamp16) o[j] = clampi(o[j], -32768, 32767);   // case 0 clamps to its 16-bit range (:409-413)
                             qv[j] = clampi(dyadic_rne(o[j], p.mq, p.eq), p.q_lo, p.q_hi);
                             ovf |= o[j] > 65535;
                         }
@@ -1417,6 +1423,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.m = a->m, p.e = a->e, p.m_id = a->m_id, p.e_id = a->e_id;
     p.m_id_s = a->m_id_scalar, p.e_id_s = a->e_id_scalar;
     p.res_in = a->res_in, p.res_in_bits = a->res_in_bits;
+    p.res_no_relu = a->res_no_relu, p.res_clamp16 = a->res_clamp16;
     p.res_out = a->res_out, p.res_out_bits = a->res_out_bits;
     p.out_q = a->out_q, p.out_bits = a->out_bits, p.q_lo = a->q_lo, p.q_hi = a->q_hi, p.mq = a->mq, p.eq = a->eq;
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
@@ -1448,7 +1455,9 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         } else {
             p.mq = 0, p.eq = 33;
         }
-        if (!dual) {
+        if (!dual && !a->res_in) {   // no identity branch at all (ABI 3, general path)
+            p.m_id_s = 0, p.e_id_s = 33;
+        } else if (!dual) {
             HAWQ_REQUIRE(a->m_id_scalar >= 0 && e_any(a->e_id_scalar), "hawq_conv2d: bad (m_id_scalar, e_id_scalar)");
             HAWQ_REQUIRE(!fast || e_fast(a->e_id_scalar), "hawq_conv2d: fast_tables needs e_id_scalar in [33,62]");
         } else {
@@ -1470,8 +1479,10 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             break;
         case HAWQ_EPI_RESIDUAL:
             HAWQ_REQUIRE(a->m && a->e, "hawq_conv2d: RESIDUAL needs m, e");
-            HAWQ_REQUIRE(dual || a->res_in, "hawq_conv2d: RESIDUAL needs res_in or a second branch");
-            HAWQ_REQUIRE(dual || a->res_in_bits == 16 || a->res_in_bits == 32, "hawq_conv2d: res_in_bits 16/32");
+            HAWQ_REQUIRE(dual || a->res_in || !fast, "hawq_conv2d: the fast RESIDUAL epilogue needs res_in or a second branch");
+            HAWQ_REQUIRE(dual || !a->res_in || a->res_in_bits == 16 || a->res_in_bits == 32, "hawq_conv2d: res_in_bits 16/32");
+            HAWQ_REQUIRE(!fast || (!a->res_no_relu && !a->res_clamp16), "hawq_conv2d: res_no_relu / res_clamp16 exist on the exact general path only (fast_tables == 0)");
+            HAWQ_REQUIRE(!a->res_no_relu || !a->res_out || a->res_out_bits == 32, "hawq_conv2d: a residual stored without ReLU is signed: res_out_bits must be 32");
             HAWQ_REQUIRE(!a->res_out || a->res_out_bits == 32 || (a->res_out_bits == 16 && a->flags),
                          "hawq_conv2d: res_out_bits 16 (with flags) or 32");
             HAWQ_REQUIRE(!a->out_q || a->out_bits == 8 || a->out_bits == 4, "hawq_conv2d: out_bits must be 4 or 8");

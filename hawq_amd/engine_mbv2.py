@@ -1,0 +1,387 @@
+"""Fused integer executor for a frozen Q_MobileNetV2 on one MI355X.
+
+The module path of ``hawq_amd.q_mobilenetv2`` moves fp32 NCHW ``integer x scale`` tensors between kernels like the reference
+does.  This plan keeps integers: int8 NHWC activations between the convs of a unit, int32 NHWC for the 16-bit values that
+flow between units (MobileNetV2's units end WITHOUT an activation, so those values are signed - the uint16 residual trick
+of the ResNet plan does not apply), three launches per unit, one hipGraph per batch shape:
+
+    input QuantAct -> init_block 3x3/2 (+ReLU6 + quant_act_int32 + unit 1's block-input QuantAct)
+    per unit:  conv1 1x1 (+ReLU6 + quant_act1) -> conv2 depthwise 3x3 (+ReLU6 + quant_act2)
+               -> conv3 1x1 (+ quant_act_int32 with / without the identity branch + next block-input QuantAct)
+    final_block 1x1 (+ReLU6 + quant_act_int32_final) -> avg-pool (+quant_act_output) -> classifier (+dequant)
+
+Integer semantics (reference: q_mobilenetv2.py:60-93, 176-209; quant_utils.py:363-456), each rounding point kept:
+  * every QuantAct without identity is fixedpoint_fn case 0: ``clamp(RNE(acc * m / 2^e))`` - including the 16-bit
+    ``quant_act_int32`` of units that change shape, which therefore CLAMPS to [-32768, 32767] (hawq_conv_args.res_clamp16);
+    with an identity it is case 1: both branches requantised separately, summed, NOT clamped, and - unlike the ResNets - no
+    ReLU follows (hawq_conv_args.res_no_relu);
+  * ReLU6 sits between a conv and its QuantAct on the fp32 value.  In integers it is ReLU plus the QuantAct's own upper
+    clamp: the QuantAct's calibrated range cannot exceed 6, so ``RNE(round(6 / S_a / S_w[c]) * m / 2^e) >= q_hi`` and the clamp
+    at ``q_hi`` decides first.  ``_relu6_is_relu`` checks exactly that inequality per channel on the host and refuses the
+    plan otherwise;
+  * channel counts are padded to multiples of 64 with zero weights, zero bias and ``m = 0`` tables: padded channels carry exact
+    zeros through every tensor;
+  * the classifier is a QuantConv2d whose reference forward runs an fp32 conv on the UN-rounded ``x / S_a``
+    (quant_modules.py:727-736): its logits carry float noise of the order of an ulp.  This plan returns
+    ``float(acc) * fl(S_w[c] * S_a)``: identical int32 accumulators, logits within 2 ulp (tests/test_gpu_network.py).
+
+All convs run the exact general kernels (``fast_tables = 0``: any e, ties handled); the depthwise layers run
+``hawq_depthwise3x3_requant``.  This is a correct integer plan, not yet a tuned one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import _lib, packing
+from .quant_modules import QuantAct, QuantBnConv2d
+from .quant_utils import quantize_weight_per_channel, requant_table
+
+
+def _pad64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+def _rng(act: QuantAct):
+    b = act.activation_bit
+    return (-(2 ** (b - 1)), 2 ** (b - 1) - 1) if act.quant_mode == 'symmetric' else (0, 2 ** b - 1)
+
+
+def _i32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
+
+
+def _padded(v, n, fill=0):
+    out = np.full(n, fill, np.int64)
+    out[:len(v)] = v
+    return out
+
+
+class _Layer:
+    """Device-resident integer parameters of one QuantBnConv2d, channel-padded."""
+
+    def __init__(self, mod: QuantBnConv2d, s_a, dev, from_buffers):
+        if not from_buffers:
+            mod.prepare(s_a)
+        w = np.rint(mod.weight_integer.detach().cpu().numpy().astype(np.float64)).astype(np.int64)
+        self.cout, cg, self.kh, self.kw = w.shape
+        self.stride, self.pad, self.groups = int(mod.conv.stride[0]), int(mod.conv.padding[0]), int(mod.conv.groups)
+        self.cin = cg * self.groups
+        self.cin_p, self.cout_p = _pad64(self.cin), _pad64(self.cout)
+        self.s_w = mod.convbn_scaling_factor.detach().float().cpu().reshape(-1)
+        b = np.clip(np.rint(mod.bias_integer.detach().cpu().numpy().astype(np.float64)), -2 ** 31, 2 ** 31 - 1).astype(np.int64)
+        self.bias = _i32(_padded(b, self.cout_p), dev)
+        self.w_host = w
+        if self.groups == 1:
+            self.w = torch.from_numpy(packing.pack_conv_weight(w, 8, self.cin_p, self.cout_p)).to(dev)
+        elif self.groups == self.cin == self.cout and (self.kh, self.kw, self.pad) == (3, 3, 1):
+            w9c = np.zeros((9, self.cout_p), np.int8)
+            w9c[:, :self.cout] = w.reshape(self.cout, 9).T
+            self.w = torch.from_numpy(w9c).to(dev)
+        else:
+            raise NotImplementedError("grouped convolutions other than depthwise 3x3 are outside MobileNetV2")
+
+    def table(self, s_a, s_out, dev):
+        """(m, e) of QuantAct(conv output): ratio S_a * S_w[c] / S_out, padded channels m = 0"""
+        m, e = requant_table(s_a, self.s_w, s_out, lift=False)
+        return _i32(_padded(m, self.cout_p), dev), _i32(_padded(e, self.cout_p, 33), dev), m, e
+
+
+def _relu6_is_relu(s_a, s_w, m, e, q_hi) -> bool:
+    """ReLU6 == ReLU + the following QuantAct's clamp, iff the requantised image of fp32 6.0 reaches q_hi in every channel.
+    The reference turns a ReLU6-saturated value into z = round(6 / S_a / S_w[c]) (fixedpoint_fn, quant_utils.py:390-392) and
+    requantises THAT; this plan requantises the larger accumulator: both land on q_hi iff RNE(z * m / 2^e) >= q_hi (exact
+    integers below; every smaller accumulator is below 6.0 in fp32 and takes the same path in both)."""
+    s_a32, s_w32 = np.float32(s_a), np.asarray(s_w, np.float32)
+    a6 = np.rint((np.float32(6.0) / s_a32 / s_w32).astype(np.float64))
+    for a, mv, ev in zip(a6, np.asarray(m, np.int64), np.asarray(e, np.int64) & 0xff):
+        a, mv, ev = int(a), int(mv), int(ev)
+        t = a * mv + (1 << (ev - 1))
+        q = t >> ev
+        if t % (1 << ev) == 0 and (q & 1):   # exact tie: round half to even
+            q -= 1
+        if q < q_hi:
+            return False
+    return True
+
+
+class MobileNetV2Engine:
+    """Callable: fp32 NCHW images on the GPU -> fp32 logits of the frozen Q_MobileNetV2 (see the module docstring)."""
+
+    def __init__(self, model, from_buffers: bool = False, use_graph: bool = True, keep_accumulators: bool = False):
+        if not model.is_frozen():
+            raise RuntimeError("MobileNetV2Engine needs a frozen model (freeze_model) - ranges must be fixed")
+        _lib.load()
+        self.model, self.from_buffers, self.use_graph, self.keep_acc = model, from_buffers, use_graph and not keep_accumulators, keep_accumulators
+        self.dev = next(model.parameters()).device
+        if self.dev.type != 'cuda':
+            raise RuntimeError("MobileNetV2Engine: move the model to the MI355X first (no CPU path)")
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._batch = self._graph = None
+        self.taps = {}
+        self._prepare()
+
+    # ------------------------------------------------------------------ host-side preparation
+    def _scale(self, act):
+        s = act.act_scaling_factor if self.from_buffers else act.compute_scale()
+        return s.detach().float().cpu().reshape(-1)[:1]
+
+    def _prepare(self):
+        m, dev, one = self.model, self.dev, torch.ones(1)
+        P = self.P = {}
+        qi = m.quant_input
+        if qi.activation_bit != 8 or qi.quant_mode != 'symmetric':
+            raise NotImplementedError("quant_input must be 8-bit symmetric (every shipped schedule)")
+        s_in = self._scale(qi)
+        P['s_in'], P['inv_s_in'] = float(s_in.item()), float((1. / s_in).item())
+
+        def act16(act):
+            if act.activation_bit != 16 or act.quant_mode != 'symmetric':
+                raise NotImplementedError("the unit-closing QuantAct must be 16-bit symmetric (every shipped schedule)")
+            return self._scale(act)
+
+        def activated(layer, s_a, act):
+            """conv -> ReLU6 -> QuantAct(case 0): table + clamp; refuses if ReLU6 is not ReLU + clamp here"""
+            s_o = self._scale(act)
+            md, ed, mh, eh = layer.table(s_a, s_o, dev)
+            lo, hi = _rng(act)
+            if not _relu6_is_relu(float(s_a.item()), layer.s_w.numpy(), mh, eh, hi):
+                raise NotImplementedError("a QuantAct range above 6.0 behind ReLU6: the integer plan folds ReLU6 into the clamp")
+            return dict(m=md, e=ed, lo=max(lo, 0), hi=hi, s=s_o)
+
+        # init block: conv -> ReLU6 -> quant_act_int32 (16 bit)
+        init = _Layer(m.init_block, s_in, dev, self.from_buffers)
+        s16 = act16(m.quant_act_int32)
+        md, ed, mh, eh = init.table(s_in, s16, dev)
+        if not _relu6_is_relu(float(s_in.item()), init.s_w.numpy(), mh, eh, 32767):
+            raise NotImplementedError("quant_act_int32 range above 6.0 behind ReLU6")
+        P['init'] = dict(layer=init, m=md, e=ed)
+        units = []
+        s_prev = s16
+        for u in m.units():
+            d = dict(residual=bool(u.residual))
+            qa = u.quant_act
+            s_a = self._scale(qa)
+            mq, eq = requant_table(s_prev, one, s_a, lift=False)
+            d['mq'], d['eq'], d['q_rng'] = int(mq[0]), int(eq[0]), _rng(qa)
+            s_x = s_a
+            d['layers'] = []
+            for conv, act in u.activated:
+                L = _Layer(getattr(u, conv), s_x, dev, self.from_buffers)
+                ent = activated(L, s_x, getattr(u, act))
+                ent['layer'] = L
+                d['layers'].append(ent)
+                s_x = ent['s']
+            proj = _Layer(u.conv3, s_x, dev, self.from_buffers)
+            s_o = act16(u.quant_act_int32)
+            md, ed, _, _ = proj.table(s_x, s_o, dev)
+            d['proj'] = dict(layer=proj, m=md, e=ed)
+            if d['residual']:
+                m1, e1 = requant_table(s_prev, one, s_o, lift=False)
+                d['m_id'], d['e_id'] = int(m1[0]), int(e1[0])
+            units.append(d)
+            s_prev = s_o
+        P['units'] = units
+        qb = m.quant_act_before_final_block
+        s_b = self._scale(qb)
+        mq, eq = requant_table(s_prev, one, s_b, lift=False)
+        P['before_final'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_rng(qb))
+        fin = _Layer(m.features.final_block, s_b, dev, self.from_buffers)
+        s_f = act16(m.quant_act_int32_final)
+        md, ed, mh, eh = fin.table(s_b, s_f, dev)
+        if not _relu6_is_relu(float(s_b.item()), fin.s_w.numpy(), mh, eh, 32767):
+            raise NotImplementedError("quant_act_int32_final range above 6.0 behind ReLU6")
+        P['final'] = dict(layer=fin, m=md, e=ed)
+        ao = m.quant_act_output
+        s8 = self._scale(ao)
+        mq, eq = requant_table(s_f, one, s8, lift=False)
+        P['out'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_rng(ao))
+        if _rng(ao)[0] < -128 or _rng(ao)[1] > 127:
+            raise NotImplementedError("quant_act_output must fit int8")
+        oc = m.output
+        if oc.bias is not None or tuple(oc.kernel_size) != (1, 1) or oc.groups != 1:
+            raise NotImplementedError("the classifier must be a bias-free 1x1 QuantConv2d")
+        if self.from_buffers or getattr(oc, "use_integer_buffers", False):
+            w_int, s_w = oc.weight_integer.detach().float().cpu(), oc.conv_scaling_factor.detach().float().cpu().reshape(-1)
+        else:
+            w_int, s_w = quantize_weight_per_channel(oc.weight, oc.weight_bit, oc.per_channel, oc.weight_percentile)
+            oc.weight_integer, oc.conv_scaling_factor = w_int.to(dev), s_w.to(dev)
+            s_w = s_w.float().cpu().reshape(-1)
+        w = np.rint(w_int.numpy().astype(np.float64)).astype(np.int64)
+        nout, k = w.shape[0], w.shape[1]
+        nout_p = _pad64(nout)
+        fscale = np.zeros(nout_p, np.float32)
+        fscale[:nout] = (s_w.view(1, -1) * s8.view(1, -1)).numpy().reshape(-1)   # fl(S_w[c] * S_a), quant_modules.py:735
+        P['fc'] = dict(w=torch.from_numpy(packing.pack_conv_weight(w.reshape(nout, k, 1, 1), 8, _pad64(k), nout_p)).to(dev),
+                       bias=_i32(np.zeros(nout_p), dev), fscale=torch.from_numpy(fscale).to(dev), nout=nout, nout_p=nout_p, k=_pad64(k))
+
+    # ------------------------------------------------------------------ launch list
+    def _conv_args(self, L, x, N, H, W):
+        a = _lib.ConvArgs()
+        a.in_, a.wgt, a.bias = x.data_ptr(), L.w.data_ptr(), L.bias.data_ptr()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, L.cin_p, L.cout_p, L.kh, L.kw, L.stride, L.pad
+        a.in_bits = a.w_bits = 8
+        a.flags = self.flags.data_ptr()
+        return a
+
+    def _tap(self, ops, keep, name, a, N, ho, wo, cout, cout_p):
+        """extra RAW launch exposing the conv's int32 accumulators (tests only)"""
+        acc = torch.empty(N * ho * wo * cout_p, dtype=torch.int32, device=self.dev)
+        r = _lib.ConvArgs()
+        C.memmove(C.byref(r), C.byref(a), C.sizeof(r))
+        r.epilogue, r.out_acc, r.res_in, r.res_out, r.out_q = _lib.EPI_RAW, acc.data_ptr(), None, None, None
+        keep += [acc, r]
+        self.taps[name] = (acc, (N, ho, wo, cout_p), cout)
+        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
+
+    def _build(self, N, H, W):
+        P, dev, sp = self.P, self.dev, self.stream.cuda_stream
+        if self._graph is not None:
+            _lib.call("hawq_graph_destroy", self._graph)
+        ops, keep, self.taps, self._graph = [], [], {}, None
+        alloc = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
+        self.x_in = alloc(N * 3 * H * W, torch.float32).view(N, 3, H, W)
+        xq_f = alloc(N * 3 * H * W, torch.float32)
+        init = P['init']['layer']
+        xq = torch.zeros(N * H * W * init.cin_p, dtype=torch.int8, device=dev)
+        # input QuantAct (quant_modules.py:271-274) then int8 NHWC, channels padded to 64
+        ops.append(partial(_lib.call, "hawq_fakequant_f32", self.x_in.data_ptr(), xq_f.data_ptr(), N * 3 * H * W, P['inv_s_in'], P['s_in'], -128, 127, sp))
+        ops.append(partial(_lib.call, "hawq_f32_nchw_to_q_nhwc", xq_f.data_ptr(), xq.data_ptr(), N, 3, H, W, init.cin_p, 8, P['s_in'], sp))
+        keep += [xq_f, xq]
+
+        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name):
+            """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo)"""
+            ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
+            a = self._conv_args(L, x, n, h, w)
+            a.epilogue, a.m, a.e = _lib.EPI_RESIDUAL, m.data_ptr(), e.data_ptr()
+            out16 = alloc(n * ho * wo * L.cout_p, torch.int32)
+            a.res_out, a.res_out_bits = out16.data_ptr(), 32
+            if res_in is not None:
+                a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = res_in.data_ptr(), 32, m_id, e_id
+            a.res_no_relu, a.res_clamp16 = int(not relu), int(clamp16)
+            q = None
+            if nxt_q is not None:
+                q = alloc(n * ho * wo * L.cout_p, torch.int8)
+                a.out_q, a.out_bits, a.mq, a.eq, (a.q_lo, a.q_hi) = q.data_ptr(), 8, nxt_q[0], nxt_q[1], nxt_q[2]
+            if self.keep_acc:
+                self._tap(ops, keep, name, a, n, ho, wo, L.cout, L.cout_p)
+            keep.extend([a, out16, q])
+            ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+            self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_p), L.cout)
+            if q is not None:
+                self.taps[name + ":next_q"] = (q, (n, ho, wo, L.cout_p), L.cout)
+            return out16, q, ho, wo
+
+        units = P['units']
+        u0 = units[0]
+        x16, q, h, w = closing(init, P['init']['m'], P['init']['e'], xq, N, H, W, None, 0, 33, True, True,
+                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block")
+        for ui, u in enumerate(units):
+            name = f"unit{ui + 1}"
+            x = q
+            for li, ent in enumerate(u['layers']):
+                L = ent['layer']
+                ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
+                out = alloc(N * ho * wo * L.cout_p, torch.int8)
+                lname = f"{name}.{'conv1' if L.groups == 1 else 'conv2'}"
+                if L.groups == 1:
+                    a = self._conv_args(L, x, N, h, w)
+                    a.epilogue, a.relu, a.m, a.e = _lib.EPI_REQUANT, 1, ent['m'].data_ptr(), ent['e'].data_ptr()
+                    a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), 8, ent['lo'], ent['hi']
+                    if self.keep_acc:
+                        self._tap(ops, keep, lname, a, N, ho, wo, L.cout, L.cout_p)
+                    keep.append(a)
+                    ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+                else:
+                    acc = alloc(N * ho * wo * L.cout_p, torch.int32) if self.keep_acc else None
+                    if acc is not None:
+                        self.taps[lname] = (acc, (N, ho, wo, L.cout_p), L.cout)
+                    ops.append(partial(_lib.call, "hawq_depthwise3x3_requant", x.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), ent['m'].data_ptr(),
+                                       ent['e'].data_ptr(), N, h, w, L.cout_p, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
+                                       None if acc is None else acc.data_ptr(), sp))
+                    keep.append(acc)
+                self.taps[lname + ":q"] = (out, (N, ho, wo, L.cout_p), L.cout)
+                keep.append(out)
+                x, h, w = out, ho, wo
+            nxt = units[ui + 1] if ui + 1 < len(units) else None
+            nq = (nxt['mq'], nxt['eq'], nxt['q_rng']) if nxt is not None else (P['before_final']['mq'], P['before_final']['eq'], P['before_final']['rng'])
+            pr = u['proj']
+            x16, q, h, w = closing(pr['layer'], pr['m'], pr['e'], x, N, h, w, x16 if u['residual'] else None, u.get('m_id', 0), u.get('e_id', 33),
+                                   False, not u['residual'], nq, name + ".conv3")
+        fin = P['final']
+        x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block")
+        cl = fin['layer'].cout_p
+        qf = alloc(N * cl, torch.int8)
+        pooled = alloc(N * cl, torch.int32) if self.keep_acc else None
+        o = P['out']
+        ops.append(partial(_lib.call, "hawq_avgpool_requant", x16.data_ptr(), 32, N, h * w, cl, qf.data_ptr(), None if pooled is None else pooled.data_ptr(),
+                           o['mq'], o['eq'], o['rng'][0], o['rng'][1], sp))
+        fc = P['fc']
+        if fc['k'] != cl:
+            raise RuntimeError("classifier width does not match the final block")
+        self.logits = alloc(N * fc['nout'], torch.float32).view(N, fc['nout'])
+        a = _lib.ConvArgs()
+        a.in_, a.wgt, a.bias = qf.data_ptr(), fc['w'].data_ptr(), fc['bias'].data_ptr()
+        a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = N, 1, 1, fc['k'], fc['nout_p'], 1, 1, 1, 0
+        a.in_bits = a.w_bits = 8
+        a.epilogue = _lib.EPI_DEQUANT
+        a.out_f32, a.fscale, a.ldo, a.n_valid = self.logits.data_ptr(), fc['fscale'].data_ptr(), fc['nout'], fc['nout']
+        if self.keep_acc:
+            self._tap(ops, keep, "output", a, N, 1, 1, fc['nout'], fc['nout_p'])
+        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+        keep += [qf, pooled, a]
+        self._ops, self._keep, self._batch = ops, keep, (N, H, W)
+
+    # ------------------------------------------------------------------ execution
+    def run_resident(self):
+        if self.use_graph:
+            if self._graph is None:
+                for op in self._ops:   # warm-up outside capture
+                    op()
+                torch.cuda.synchronize(self.dev)
+                _lib.call("hawq_graph_begin", self.stream.cuda_stream)
+                try:
+                    for op in self._ops:
+                        op()
+                finally:
+                    g = C.c_void_p()
+                    _lib.call("hawq_graph_end", self.stream.cuda_stream, C.byref(g))
+                self._graph = g
+            _lib.call("hawq_graph_launch", self._graph, self.stream.cuda_stream)
+        else:
+            for op in self._ops:
+                op()
+
+    def __call__(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("MobileNetV2Engine: input must be on the MI355X (no CPU path)")
+        N, Cc, H, W = x.shape
+        if Cc != 3:
+            raise ValueError("expected [N,3,H,W] images")
+        if self._batch != (N, H, W):
+            self._build(N, H, W)
+        cur = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.x_in.copy_(x, non_blocking=True)
+            self.run_resident()
+            out = self.logits.clone()
+        cur.wait_stream(self.stream)
+        return out
+
+    def tap(self, name):
+        """int32 / int8 NHWC tensor of a tapped stage as an NCHW int64 numpy array without the padding channels."""
+        t, shp, c = self.taps[name]
+        a = t.cpu().numpy().reshape(shp).astype(np.int64)[..., :c]
+        return a.transpose(0, 3, 1, 2)
+
+    def __del__(self):
+        try:
+            if self._graph is not None:
+                _lib.call("hawq_graph_destroy", self._graph)
+        except Exception:
+            pass

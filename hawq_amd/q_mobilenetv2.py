@@ -12,11 +12,13 @@ The forward is one rule applied along the layer tables below: ``conv -> ReLU6 ->
 for every activated layer, the bare ``conv`` for a unit's projection, and the unit-closing ``quant_act_int32`` in its
 residual form (fixedpoint_fn case 1, quant_utils.py:416-456) when the float unit keeps its input shape.
 
-Execution is module by module through the HIP library in the reference's fp32-tuple convention: 1x1 convs on the MFMA
-implicit-GEMM kernel, the 3x3 depthwise convs on ``hawq_depthwise3x3`` (adapters.hip), every QuantAct on
-``hawq_fixedpoint_f32``.  The fused integer plan (hawq_amd.engine) covers the ResNets; MobileNetV2 in that plan is the next
-widening of SURVEY.md 8(f).3 (its QuantConv2d classifier runs the reference's fp32 conv on un-rounded ``x / S_a``,
-quant_modules.py:727-736, which an integer path reproduces to 2 ulp, not bit for bit)."""
+Execution: a frozen, eval-mode network called on a CUDA tensor runs the FUSED INTEGER PLAN of
+``hawq_amd.engine_mbv2.MobileNetV2Engine`` (int8 tensors between the convs of a unit, int32 for the signed 16-bit values between
+units, three launches per unit, hipGraph replay).  Otherwise (un-frozen = range calibration, or ``fused = False``) it steps module by
+module through the same HIP library in the reference's fp32-tuple convention: 1x1 convs on the MFMA implicit-GEMM kernel, the
+3x3 depthwise convs on ``hawq_depthwise3x3`` (adapters.hip), every QuantAct on ``hawq_fixedpoint_f32``.  Either way the
+QuantConv2d classifier - whose reference forward runs an fp32 conv on un-rounded ``x / S_a`` (quant_modules.py:727-736) - is
+reproduced to 2 ulp with identical int32 accumulators, not bit for bit."""
 from __future__ import annotations
 
 import torch.nn as nn
@@ -101,6 +103,9 @@ class Q_MobileNetV2(nn.Module):
         self.quant_act_output = QuantAct()
         self.output = QuantConv2d()
         self.output.set_param(model.output)
+        self.fused = True          # use the integer plan when frozen + eval + CUDA
+        self._engine = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._on_state_dict_loaded())
 
     def units(self):
         for sname, stage in self.features.named_children():
@@ -108,6 +113,12 @@ class Q_MobileNetV2(nn.Module):
                 yield from stage.children()
 
     def forward(self, x):
+        if self.fused and x.is_cuda and not self.training and self.is_frozen():
+            return self.engine()(x)
+        return self.forward_modules(x)
+
+    def forward_modules(self, x):
+        """Module-by-module forward (q_mobilenetv2.py:176-209)."""
         x, scale = self.quant_input(x)
         x, scale = _activated(self.init_block, self.quant_act_int32, x, scale)
         for unit in self.units():
@@ -119,15 +130,28 @@ class Q_MobileNetV2(nn.Module):
         x, _ = self.output(x, scale)
         return x.flatten(1)
 
-    forward_modules = forward
-
     def is_frozen(self):
         acts = [m for m in self.modules() if isinstance(m, QuantAct)]
         convs = [m for m in self.modules() if isinstance(m, (QuantBnConv2d, QuantConv2d))]
         return all((not m.running_stat) for m in acts) and all(m.fix_flag for m in convs)
 
-    def invalidate_engine(self):   # API symmetry with the ResNets (there is no fused plan to drop)
-        pass
+    def engine(self, **kw):
+        """Build (or return the cached) fused integer executor for this frozen network."""
+        from .engine_mbv2 import MobileNetV2Engine
+        if self._engine is None or kw:
+            opts = {k: v for k, v in getattr(self, "engine_defaults", {}).items() if k == "from_buffers"}
+            self._engine = MobileNetV2Engine(self, **{**opts, **kw})
+        return self._engine
+
+    def invalidate_engine(self):
+        self._engine = None
+
+    def _on_state_dict_loaded(self):
+        from .quant_modules import trust_integer_buffers
+        self.invalidate_engine()
+        trust_integer_buffers(self, False)
+        if getattr(self, "engine_defaults", None):
+            self.engine_defaults = dict(self.engine_defaults, from_buffers=False)
 
 
 def q_mobilenetv2_w1(model):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HAWQ_ABI_VERSION 2
+#define HAWQ_ABI_VERSION 3
 
 const char *hawq_last_error(void);
 int hawq_abi_version(void);
@@ -120,6 +120,13 @@ typedef struct hawq_conv_args {
                              are what the 3x3 band kernels' LDS-DMA fill wants (64 consecutive pixels of one plane
                              are one contiguous KiB); only those kernels read them.                              */
     int32_t out_planar;   /* same for `out_q` (fast-contract REQUANT / RESIDUAL epilogues only)                  */
+    /* ABI 3 - RESIDUAL epilogue of networks whose units end WITHOUT an activation (MobileNetV2's linear bottleneck,
+       q_mobilenetv2.py:60-93): exact general path only (fast_tables == 0), 32-bit residual tensors.
+       res_no_relu: 1 = the requantised sum is stored as is (signed); 0 = ReLU after it (the ResNets, q_resnet.py:258).
+       res_clamp16: 1 = clamp the result to [-32768, 32767]: quant_act_int32 WITHOUT an identity branch is fixedpoint_fn case 0,
+                    which clamps to its 16-bit range (quant_utils.py:409-413); with an identity (case 1) nothing clamps (:456).
+       With res_in == NULL and in2 == NULL there is no identity branch: o = requant(acc + bias).                          */
+    int32_t res_no_relu, res_clamp16;
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
@@ -246,6 +253,14 @@ int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const int32_t *bias
  * [N][Ho][Wo][C] int32 (exact).  C % 4 == 0, stride 1 or 2. */
 int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, int32_t N, int32_t H, int32_t W, int32_t C,
                       int32_t stride, int32_t *out_acc, void *stream);
+
+/* The same with the conv's activation + QuantAct fused (conv2 -> ReLU6 -> quant_act2 of a MobileNetV2 unit, q_mobilenetv2.py:71-73;
+ * ReLU6 == ReLU + the QuantAct's own clamp: its calibrated range never exceeds 6): out_q[N][Ho][Wo][C] int8 =
+ * clamp(dyadic_rne(relu ? max(acc + bias, 0) : acc + bias, m[c], e[c]), q_lo, q_hi) with exact (tie-aware) rounding;
+ * out_acc (optional) additionally receives the int32 accumulators. */
+int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e,
+                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu, int32_t q_lo, int32_t q_hi,
+                              int8_t *out_q, int32_t *out_acc, void *stream);
 
 /* One separable pass of Pillow's 8-bit antialiased resampling (what torchvision's Resize(256) does to the decoded PIL image,
  * quant_train.py:428-440): uint8 HWC in / out, int32 coefficients with 22 fractional bits (hawq_amd/image.py builds them as

@@ -118,8 +118,13 @@ def mobilenet_fixture(scheme, batch=2):
     q = ref_live.build_reference_model("mobilenetv2_w1", scheme, seed=0)
     x = synthetic_images(batch, seed=0)
     ref_live.calibrate_and_freeze(q, x)
-    with torch.no_grad():
-        y = q(x)
+    # one frozen forward with taps: raw F.conv2d outputs (= int32 accumulators incl. bias) and every QuantAct's integer output
+    act_out = {}
+    hooks = [m.register_forward_hook(lambda mod, i, o, n=n: act_out.__setitem__(n, torch.round(o[0] / o[1].reshape(-1)[0]).to(torch.int64)))
+             for n, m in q.named_modules() if type(m).__name__ == "QuantAct"]
+    y, conv_taps, _ = ref_live.forward_with_taps(q, x)
+    for hk in hooks:
+        hk.remove()
     ours = build_quantized_model("mobilenetv2_w1", scheme, seed=0)
     out = dict(logits=y.numpy(), top1=y.argmax(1).numpy(), input_sha=np.array(hashlib.sha256(x.numpy().tobytes()).hexdigest()))
     acts = [(n, m) for n, m in q.named_modules() if type(m).__name__ == "QuantAct"]
@@ -148,8 +153,15 @@ def mobilenet_fixture(scheme, batch=2):
         w_own = mm.weight_integer.detach().float().numpy()
         for idx in np.nonzero(w_own.reshape(-1) != w_ref.reshape(-1))[0]:
             patches.append((li, int(idx), int(w_ref.reshape(-1)[idx])))
+    assert len(conv_taps) == len(convs)   # call order == registration order in this graph
+    sys.path.insert(0, HERE)
+    from make_golden import digest
     out.update(conv_names=np.array(names), conv_scale=np.concatenate(scales), conv_bias=np.concatenate(biases),
-               conv_wsha=np.array(shas), conv_wpatch=np.array(patches, np.int64).reshape(-1, 3))
+               conv_wsha=np.array(shas), conv_wpatch=np.array(patches, np.int64).reshape(-1, 3),
+               # 3-word digests (make_golden.digest, NCHW order) of rint(raw conv output) per conv and of every QuantAct's integers
+               conv_accdigest=np.stack([digest(np.rint(t.numpy().astype(np.float64)).astype(np.int64)) for t in conv_taps]),
+               act_outdigest=np.stack([digest(act_out[n].numpy()) for n, _ in acts]),
+               act_outmax=np.array([int(act_out[n].abs().max()) for n, _ in acts], np.int64))
     np.savez_compressed(os.path.join(HERE, f"net_mobilenetv2_w1_{scheme}_b{batch}.npz"), **out)
     print("mobilenetv2_w1", scheme, "top1", out["top1"], "weight patches", len(patches), flush=True)
 

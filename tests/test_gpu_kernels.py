@@ -716,6 +716,86 @@ def test_depthwise3x3_matches_the_grouped_kernel_and_numpy(lib, shape):
     assert lib.load().hawq_depthwise3x3(xd.data_ptr(), w9.data_ptr(), None, n, h, w, c + 1, stride, out_d.data_ptr(), None) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 9, 7, 32, 1, 1), (1, 14, 14, 96, 2, 1), (3, 5, 6, 8, 2, 0), (1, 113, 57, 24, 2, 1), (2, 3, 3, 4, 1, 0)])
+def test_depthwise3x3_requant_matches_accumulators_plus_host_dyadic(lib, orc, shape):
+    """hawq_depthwise3x3_requant (MobileNetV2's conv2 fused with the QuantAct behind it: per-channel dyadic requant of the
+    optionally rectified accumulator, clamp to the activation range) against hawq_depthwise3x3's accumulators pushed through
+    the oracle's dyadic RNE; the optional accumulator output must equal the plain kernel's."""
+    from hawq_amd.quant_utils import requant_table
+    n, h, w, c, stride, relu = shape
+    rng = np.random.default_rng(c * 17 + h)
+    x = rng.integers(-128, 128, (n, h, w, c)).astype(np.int8)
+    wt = rng.integers(-127, 128, (c, 3, 3)).astype(np.int8)
+    b = rng.integers(-30000, 30000, c).astype(np.int32)
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    ratio = torch.from_numpy(rng.uniform(2e-4, 3e-3, c).astype(f32))
+    m, e = requant_table(ratio, torch.ones(c), torch.ones(1), lift=False)
+    xd, w9, bd, md, ed = dev(x), dev(np.ascontiguousarray(wt.reshape(c, 9).T)), dev(b), dev(m), dev(e)
+    acc = torch.zeros(n * ho * wo * c, dtype=torch.int32, device='cuda')
+    lib.call("hawq_depthwise3x3", xd.data_ptr(), w9.data_ptr(), bd.data_ptr(), n, h, w, c, stride, acc.data_ptr(), stream())
+    lo, hi = (0, 127) if relu else (-128, 127)
+    a = acc.cpu().numpy().astype(np.int64).reshape(n, ho, wo, c)
+    ref = odyadic(orc, (np.maximum(a, 0) if relu else a).transpose(0, 3, 1, 2), m, e, (lo, hi)).transpose(0, 2, 3, 1)
+    for keep_acc in (True, False):
+        q = torch.full((n * ho * wo * c,), 77, dtype=torch.int8, device='cuda')
+        acc2 = torch.zeros_like(acc)
+        lib.call("hawq_depthwise3x3_requant", xd.data_ptr(), w9.data_ptr(), bd.data_ptr(), md.data_ptr(), ed.data_ptr(), n, h, w, c, stride,
+                 relu, lo, hi, q.data_ptr(), acc2.data_ptr() if keep_acc else None, stream())
+        assert np.array_equal(q.cpu().numpy().reshape(n, ho, wo, c).astype(np.int64), ref), (shape, keep_acc)
+        assert not keep_acc or torch.equal(acc2, acc)
+    assert ref.min() < 0 or relu
+    assert lib.load().hawq_depthwise3x3_requant(xd.data_ptr(), w9.data_ptr(), None, md.data_ptr(), ed.data_ptr(), n, h, w, c, stride, 0, -129, 127,
+                                                q.data_ptr(), None, None) != 0
+
+
+@pytest.mark.parametrize("mode", ["linear", "linear_add", "relu_clamp_noid"])
+def test_residual_epilogue_without_relu_and_with_the_16_bit_clamp(lib, orc, mode):
+    """The general RESIDUAL epilogue's MobileNetV2 switches (hawq_conv_args.res_no_relu / res_clamp16 / res_in == NULL):
+    a linear bottleneck ends without an activation, so the 32-bit carrier holds signed values - requant(acc) [+ identity],
+    clamped to the signed 16-bit range only where the reference's QuantAct runs fixedpoint_fn case 0
+    (quant_modules.py:239-262), then requantised for the next unit with a signed clamp."""
+    from hawq_amd.quant_utils import requant_table
+    rng = np.random.default_rng(len(mode))
+    n, h, w, cin, cout = 2, 9, 7, 64, 128
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 1, 8, 8)
+    a, keep = conv_args(lib, x, wt, b, 1, 0, 8, 8)
+    acc = orc.conv2d(x, wt, b, 1, 0)
+    ratio = torch.from_numpy(rng.uniform(0.5, 3.0, cout).astype(f32))   # wide enough to leave the 16-bit range
+    m2, e2 = requant_table(ratio, torch.ones(cout), torch.ones(1), lift=False)
+    v = odyadic(orc, acc, m2, e2)
+    if mode == "linear_add":
+        res = rng.integers(-30000, 30000, (n, cout, h, w)).astype(np.int64)
+        m1, e1 = requant_table(torch.tensor([0.81]), torch.ones(1), torch.ones(1), lift=False)
+        keep['res'] = dev(nhwc(res).astype(np.int32))
+        a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = keep['res'].data_ptr(), 32, int(m1[0]), int(e1[0])
+        v = v + odyadic(orc, res, m1, e1)
+        a.res_no_relu, a.res_clamp16 = 1, 0
+    elif mode == "linear":
+        a.res_no_relu, a.res_clamp16 = 1, 1
+        v = np.clip(v, -32768, 32767)
+    else:
+        a.res_no_relu, a.res_clamp16 = 0, 1
+        v = np.clip(np.maximum(v, 0), -32768, 32767)
+    assert np.abs(v).max() >= 32767 or mode == "linear_add"
+    mq, eq = requant_table(torch.tensor([0.0031]), torch.ones(1), torch.ones(1), lift=False)
+    lo, hi = (0, 127) if mode == "relu_clamp_noid" else (-128, 127)
+    ref_q = odyadic(orc, v, mq, eq, (lo, hi))
+    md, ed = dev(m2), dev(e2)
+    flags = torch.zeros(1, dtype=torch.int32, device='cuda')
+    out_res = torch.zeros(v.size, dtype=torch.int32, device='cuda')
+    out_q = torch.zeros(v.size, dtype=torch.int8, device='cuda')
+    a.epilogue, a.m, a.e, a.flags = lib.EPI_RESIDUAL, md.data_ptr(), ed.data_ptr(), flags.data_ptr()
+    a.res_out, a.res_out_bits = out_res.data_ptr(), 32
+    a.out_q, a.out_bits, a.q_lo, a.q_hi, a.mq, a.eq = out_q.data_ptr(), 8, lo, hi, int(mq[0]), int(eq[0])
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    got = out_res.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2)
+    assert np.array_equal(got, v)
+    assert np.array_equal(out_q.cpu().numpy().astype(np.int64).reshape(n, h, w, cout).transpose(0, 3, 1, 2), ref_q)
+    # the fast (uint16) kernels have no signed carrier: the switches are refused there
+    a.fast_tables, a.res_out_bits = 1, 16
+    assert lib.load().hawq_conv2d(C.byref(a), None) != 0
+
+
 def test_range_statistics_kernels_match_reference_kats(lib):
     """hawq_minmax_f32 / hawq_kthvalue_f32 behind get_percentile_min_max and the un-frozen QuantAct (min/max and
     percentile ranges, initialisation + momentum / running-extremum updates) against the live reference's numbers."""

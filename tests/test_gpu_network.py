@@ -241,7 +241,8 @@ def test_mobilenetv2_matches_reference_golden(scheme):
         off += sc.size
     bad = [n for i, (n, m) in enumerate(acts) if float(m.x_min) != float(fx["act_x_min"][i]) or float(m.x_max) != float(fx["act_x_max"][i])]
     assert not (same_scales and bad), bad[:4]   # (a weight scale one ulp off - DESIGN.md 2.2 - may move later ranges)
-    y_own = model(x.cuda())
+    with torch.no_grad():
+        y_own = model.forward_modules(x.cuda())
     assert np.array_equal(y_own.argmax(1).cpu().numpy(), fx["top1"])
     # the rigorous comparison: the reference's ranges and integer buffers
     for i, (n, m) in enumerate(acts):
@@ -267,7 +268,8 @@ def test_mobilenetv2_matches_reference_golden(scheme):
         m.use_integer_buffers = True
         m._prep_key = None
         off += co
-    y = model(x.cuda()).cpu().numpy()
+    with torch.no_grad():
+        y = model.forward_modules(x.cuda()).cpu().numpy()
     # The classifier is a QuantConv2d: the reference runs its fp32 conv on the UN-ROUNDED x / S_a (quant_modules.py:727-736), so
     # its logits carry a float error of the order of an ulp that no integer path reproduces; the integers they stand for
     # - rint(logit / (S_w[c] * S_a)) = the int32 accumulators - must agree, and the logits to within 2 ulp.
@@ -277,3 +279,104 @@ def test_mobilenetv2_matches_reference_golden(scheme):
     assert np.array_equal(y.argmax(1), fx["top1"])
     if same_scales and not bad:
         assert np.array_equal(np.rint(y_own.cpu().numpy() / s_out), np.rint(fx["logits"] / s_out))
+
+
+def _load_mobilenet_reference_state(model, fx):
+    """the reference run's frozen ranges and integer checkpoint (tests/golden/net_mobilenetv2_*.npz) into `model`"""
+    import hashlib
+    from hawq_amd.quant_modules import QuantAct, QuantBnConv2d, QuantConv2d
+    acts = [(n, m) for n, m in model.named_modules() if isinstance(m, QuantAct)]
+    convs = [(n, m) for n, m in model.named_modules() if isinstance(m, (QuantBnConv2d, QuantConv2d))]
+    assert [n for n, _ in acts] == [str(n) for n in fx["act_names"]] and [n for n, _ in convs] == [str(n) for n in fx["conv_names"]]
+    for i, (n, m) in enumerate(acts):
+        m.x_min.fill_(float(fx["act_x_min"][i])), m.x_max.fill_(float(fx["act_x_max"][i]))
+        m.compute_scale()
+        assert m.act_scaling_factor.item() == float(fx["act_scale"][i]), n
+    off = 0
+    for li, (n, m) in enumerate(convs):
+        w = m.weight_integer.detach().cpu().numpy().copy()
+        for l, idx, val in fx["conv_wpatch"]:
+            if l == li:
+                w.reshape(-1)[idx] = val
+        assert hashlib.sha256(np.ascontiguousarray(w.astype(np.int8)).tobytes()).hexdigest() == str(fx["conv_wsha"][li]), n
+        co, dev = w.shape[0], m.weight_integer.device
+        m.weight_integer = torch.from_numpy(w).to(dev)
+        sc = torch.from_numpy(fx["conv_scale"][off:off + co].copy()).to(dev)
+        if isinstance(m, QuantBnConv2d):
+            m.convbn_scaling_factor = sc
+            m.bias_integer = torch.from_numpy(fx["conv_bias"][off:off + co].astype(np.float32)).to(dev)
+        else:
+            m.conv_scaling_factor = sc
+        off += co
+    return acts, convs
+
+
+@pytest.mark.parametrize("scheme", ["uniform8", "uniform4", "bops_0.5"])
+def test_mobilenetv2_integer_plan_matches_reference_golden(scheme):
+    """The FUSED INTEGER PLAN of Q_MobileNetV2 (hawq_amd/engine_mbv2.py: int8 between the convs of a unit, int32 for the signed
+    16-bit values between units, depthwise 3x3 with a fused requant, linear-bottleneck residuals without ReLU, ReLU6 folded
+    into the clamps, channels padded to 64) against the live reference's fixture (tests/golden/make_kat_extra.py --mobilenet):
+    on the reference's frozen ranges and integer checkpoint EVERY conv's int32 accumulators (54 convs incl. the 17 depthwise
+    layers and the classifier) and EVERY tapped QuantAct's integers (block inputs, quant_act1/2, the 16-bit unit outputs with
+    and without identity) must have the fixture's digests; logits as the module path: identical integers, within 2 ulp, same
+    top-1.  Also: own preparation, plan vs module path; hipGraph replay."""
+    from hawq_amd.api import build_quantized_model, calibrate
+    from hawq_amd.engine_mbv2 import MobileNetV2Engine
+    from hawq_amd.quant_modules import trust_integer_buffers
+    fx = H.load(f"net_mobilenetv2_w1_{scheme}_b2.npz")
+    x = _images()
+    assert H.sha(x.numpy()) == str(fx["input_sha"])
+    model = build_quantized_model("mobilenetv2_w1", scheme, seed=0).cuda()
+    calibrate(model, x.cuda())
+    with torch.no_grad():
+        y_mod = model.forward_modules(x.cuda())
+    y_plan = model(x.cuda())                      # frozen + eval + CUDA -> the fused plan (own, IEEE preparation)
+    assert model._engine is not None and model._engine.use_graph
+    s_own = model.output.conv_scaling_factor.cpu().numpy().reshape(1, -1).astype(np.float64) * float(model.quant_act_output.act_scaling_factor)
+    assert np.array_equal(np.rint(y_plan.cpu().numpy() / s_own), np.rint(y_mod.cpu().numpy() / s_own))
+    assert torch.equal(model(x.cuda()), y_plan)   # graph replay
+    # the rigorous comparison: the reference's ranges and integer buffers, every stage tapped
+    acts, convs = _load_mobilenet_reference_state(model, fx)
+    trust_integer_buffers(model, True)
+    model.invalidate_engine()
+    eng = MobileNetV2Engine(model, from_buffers=True, keep_accumulators=True)
+    y = eng(x.cuda()).cpu().numpy()
+    units = [n[:-len(".quant_act")] for n, _ in acts if n.endswith(".quant_act")]
+    unit_of = {u: f"unit{k + 1}" for k, u in enumerate(units)}
+
+    def conv_tap(n):
+        if n in ("init_block", "output"):
+            return n
+        if n == "features.final_block":
+            return "final_block"
+        u, c = n.rsplit(".", 1)
+        return f"{unit_of[u]}.{c}"
+
+    for li, (n, _) in enumerate(convs):
+        assert np.array_equal(H.digest(eng.tap(conv_tap(n))), fx["conv_accdigest"][li]), n
+    checked = 0
+    for ai, (n, _) in enumerate(acts):
+        if n == "quant_act_int32":
+            tap = "init_block:out16"
+        elif n == "quant_act_before_final_block":
+            tap = f"unit{len(units)}.conv3:next_q"
+        elif n == "quant_act_int32_final":
+            tap = "final_block:out16"
+        elif n.endswith(".quant_act"):
+            k = units.index(n[:-len(".quant_act")])
+            tap = "init_block:next_q" if k == 0 else f"unit{k}.conv3:next_q"
+        elif n.endswith(".quant_act1") or n.endswith(".quant_act2"):
+            tap = f"{unit_of[n.rsplit('.', 1)[0]]}.conv{n[-1]}:q"
+        elif n.endswith(".quant_act_int32"):
+            tap = f"{unit_of[n.rsplit('.', 1)[0]]}.conv3:out16"
+        else:
+            continue   # quant_input / quant_act_output: covered by the first conv's accumulators / the classifier's
+        assert np.array_equal(H.digest(eng.tap(tap)), fx["act_outdigest"][ai]), (n, tap)
+        checked += 1
+    assert checked == len(acts) - 2
+    s_out = model.output.conv_scaling_factor.cpu().numpy().reshape(1, -1).astype(np.float64) * float(model.quant_act_output.act_scaling_factor)
+    assert np.array_equal(np.rint(y / s_out), np.rint(fx["logits"] / s_out))
+    assert np.abs(y - fx["logits"]).max() <= 2 ** -22 * np.abs(fx["logits"]).max()
+    assert np.array_equal(y.argmax(1), fx["top1"])
+    # the same state through the model's own entry point (graph, no taps)
+    assert np.array_equal(np.rint(model(x.cuda()).cpu().numpy() / s_out), np.rint(fx["logits"] / s_out))

@@ -44,13 +44,13 @@ fetch_kb = (tot[("FETCH_SIZE", 12)] - tot[("FETCH_SIZE", 2)]) / 10
 write_kb = (tot[("WRITE_SIZE", 12)] - tot[("WRITE_SIZE", 2)]) / 10
 b = json.loads(open("$O/${tag}_bench.json").readline())
 out = {b["config"]["workload"]: {
-    "bytes_per_launch": round((2 * fetch_kb + write_kb) * 1000.0), "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+    "bytes_per_launch": round((2 * fetch_kb + write_kb) * 1024.0), "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
     "git_head": "${GRAFT_HEAD:-unknown}", "tag": "$tag", "fused_pairs": b["config"].get("fused_pairs", []),
     # the plan the counters were collected for (replayed via HAWQ_TILES / HAWQ_ER_TILES / HAWQ_CHAINS): bench.py prints whether a later run's plan is the same
     "plan": {"tiles": b["config"]["autotuned_tiles"], "fused_variants": b["config"]["fused_variants"], "chains": b["config"]["concurrent_sub_batches"]},
     "config": f"{b['config']['concurrent_sub_batches']} concurrent sub-batches, tiles {b['config']['autotuned_tiles']}, fused variants {b['config']['fused_variants']} replayed",
     "upper_bound_note": "FETCH_SIZE / WRITE_SIZE count requests at the L2's memory side; Infinity-Cache hits are included (profiles/r03_pmc_calibration.md), so this is an upper bound on HBM bytes",
-    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only), counter summed over ALL dispatches of bench.py --no-cpu-baseline --no-extra --warmup 1 at --steps 12 minus the same at --steps 2, divided by 10 forwards (tools/profile_round.sh, tools/pmc_total.py); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16 B/lane streams); KB = 1000 B"}}
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace only), counter summed over ALL dispatches of bench.py --no-cpu-baseline --no-extra --warmup 1 at --steps 12 minus the same at --steps 2, divided by 10 forwards (tools/profile_round.sh, tools/pmc_total.py); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16 B/lane streams); the counters report KiB (profiles/r03_pmc_calibration.md: 32 MiB written = 32 768)"}}
 json.dump(out, open("$O/${tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
