@@ -54,6 +54,28 @@ def setup_workload(arch, scheme, batch, dev, seed, shard=None):
     return model, eng, x
 
 
+def mobilenet_line(batch, dev, steps):
+    import numpy as np
+    from hawq_amd import roofline
+    from hawq_amd.api import build_quantized_model, calibrate
+    from hawq_amd.skeleton import synthetic_images
+
+    model = build_quantized_model("mobilenetv2_w1", "uniform8", seed=0).to(dev)
+    calibrate(model, synthetic_images(8, seed=0).to(dev))
+    x = synthetic_images(batch, seed=1).to(dev)
+    eng = model.engine()
+    y = eng(x)
+    with torch.no_grad():
+        y_mod = model.forward_modules(x[:8])
+    s = (model.output.conv_scaling_factor.reshape(1, -1).double() * model.quant_act_output.act_scaling_factor.double()).cpu().numpy()
+    same = bool(np.array_equal(np.rint(y[:8].cpu().numpy() / s), np.rint(y_mod.cpu().numpy() / s)))
+    wall, gpu_ms, blk = timed_steps(eng, steps, 5, 1)
+    return {"images_per_s": round(batch * steps / wall, 1), "gpu_ms": round(gpu_ms, 4), "gpu_ms_std": blk["std_ms"],
+            "launches": len(eng._ops), "fast_requant_launches": eng.n_fast, "plan_bytes_per_image": int(eng.plan_bytes // batch),
+            "hbm_frac": round(eng.plan_bytes / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4),
+            "plan_equals_module_path": same}
+
+
 def golden_parity(arch, scheme, batch, seed, logits, lo=0):
     """Compare logits of the benchmarked workload with the CPU oracle's (tests/golden/b128_*.npz, all 128 images;
     written by tests/golden/make_b128.py).  None if there is no fixture for this workload."""
@@ -533,6 +555,11 @@ def main():
                 "concurrent_sub_batches": e2.chains}
             del m2, e2, x2
             torch.cuda.empty_cache()
+        # MobileNetV2 (w1, W8A8) through its own fused integer plan (hawq_amd/engine_mbv2.py).  There is no CPU
+        # oracle for this family; the check beside the number is plan vs the module-by-module path (independent kernels and
+        # fp32 glue) on the first 8 images - identical output integers (tests/test_gpu_network.py pins both to the live
+        # reference's per-layer digests)
+        extra["mobilenetv2_w1_uniform8_b%d" % args.batch] = mobilenet_line(args.batch, dev, n2)
         # what ONE GPU runs when the batch of 128 is sharded over 2 / 4 / 8 ranks (strong scaling):
         # the first 64 / 32 / 16 images of the headline workload, same engine configuration
         if args.batch == 128:

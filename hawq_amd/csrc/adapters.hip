@@ -220,72 +220,132 @@ extern "C" int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const in
 // ------------------------------------------------------------------------------------------------------------------
 // Depthwise 3x3 convolution (MobileNetV2's conv2, q_mobilenetv2.py:46-48; F.conv2d(groups = C), quant_modules.py:489-494):
 // int8 NHWC in, weights tap-major [3][3][C] (so that the 4 channels a thread owns are one dword per tap), exact int32 NHWC
-// accumulators out.  A thread owns 4 consecutive channels of DW_PX horizontally adjacent output pixels: its 9 weight dwords
-// stay in registers and neighbouring outputs share input columns (stride 1: 3 x (DW_PX + 2) dword loads for DW_PX outputs
-// instead of 9 each); consecutive lanes own consecutive channel groups, so every load / store instruction of a wave covers
-// whole 64..256-byte runs of the NHWC rows.  9 MACs per output: the layer is bound by its own bytes, not a matrix-pipe shape.
+// accumulators and / or the requantised int8 tensor out.
+//
+// The layer is 9 MACs per output: what it costs is bytes and VALU issue, so the kernel is built around both.
+//   * A thread owns 4 consecutive channels of DW_PX horizontally adjacent output pixels and walks a BAND of output rows with a
+//     three-row register window of packed input dwords: every input row is fetched once per band (the band's two halo rows
+//     aside) instead of once per output row it feeds.  The first version mapped every output row to another workgroup; the
+//     rows of one image then landed on different XCDs and each of their L2s fetched the same input row again (3.2 TB/s of
+//     fabric traffic for 0.9 TB/s of tensor bytes on the 112 x 112 layers).
+//   * Consecutive lanes own consecutive channel groups, so each load / store instruction of a wave covers whole 64..256-byte
+//     runs of the NHWC rows; all loads of an input row are issued back to back with clamped addresses (no branches), border
+//     zeros come from a select.
+//   * One MAC is ONE instruction and the packed operands are never unpacked: v_dot4_i32_i8 of the packed input dword with a
+//     copy of the tap's weight dword that keeps only byte j adds x_j * w_j to accumulator j.  The 36 masked weight dwords are
+//     loop-invariant registers.
 namespace {
 constexpr int DW_PX = 4;
+constexpr int DW_MAX_BAND = 8;
+
 // REQ: conv2 -> ReLU -> QuantAct fused (exact dyadic_rne per channel table), int8 out; `out` (int32) then optional
-template <bool REQ>
+template <bool REQ, int S>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ w9c, const int32_t *__restrict__ bias,
-                                                           int N, int H, int W, int C, int stride, int Ho, int Wo, int32_t *__restrict__ out,
+                                                           int N, int H, int W, int C, int Ho, int Wo, int band, int32_t *__restrict__ out,
                                                            const int32_t *__restrict__ mult, const int32_t *__restrict__ expo, int relu, int q_lo, int q_hi,
                                                            int8_t *__restrict__ out_q) {
-    const int cgs = C >> 2, wq = (Wo + DW_PX - 1) / DW_PX;
-    const long long total = (long long)N * Ho * wq * cgs;
+    constexpr int NC = (DW_PX - 1) * S + 3;   // input columns under DW_PX outputs
+    const int cgs = C >> 2, wq = (Wo + DW_PX - 1) / DW_PX, bands = (Ho + band - 1) / band;
+    const long long total = (long long)N * bands * wq * cgs;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % cgs);
-        long long m = idx / cgs;
-        const int xq = (int)(m % wq);
-        m /= wq;
-        const int oy = (int)(m % Ho), n = (int)(m / Ho), ox0 = xq * DW_PX;
-        int wreg[9];
+        long long rest = idx / cgs;
+        const int xq = (int)(rest % wq);
+        rest /= wq;
+        const int bi = (int)(rest % bands), n = (int)(rest / bands), ox0 = xq * DW_PX;
+        const int oy0 = bi * band, oy1 = min(oy0 + band, Ho);
+        int wm[9][4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wreg[t] = *reinterpret_cast<const int *>(w9c + (size_t)t * C + 4 * cg);
-        int acc[DW_PX][4];
+        for (int t = 0; t < 9; ++t) {
+            const int ww = *reinterpret_cast<const int *>(w9c + (size_t)t * C + 4 * cg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wm[t][j] = ww & (0xff << (8 * j));
+        }
         const v4i b4 = bias ? *reinterpret_cast<const v4i *>(bias + 4 * cg) : v4i{0, 0, 0, 0};
+        v4i m4 = {0, 0, 0, 0}, e4 = {0, 0, 0, 0};
+        if constexpr (REQ) m4 = *reinterpret_cast<const v4i *>(mult + 4 * cg), e4 = *reinterpret_cast<const v4i *>(expo + 4 * cg);
+        // column offsets (clamped) and validity of the NC input columns
+        int coff[NC];
+        unsigned cmask = 0;
 #pragma unroll
-        for (int p = 0; p < DW_PX; ++p)
+        for (int c = 0; c < NC; ++c) {
+            const int ix = ox0 * S - 1 + c;
+            cmask |= ((unsigned)ix < (unsigned)W ? 1u : 0u) << c;
+            coff[c] = min(max(ix, 0), W - 1) * C;
+        }
+        const int8_t *img = in + (size_t)n * H * W * C + 4 * cg;
+        auto load_row = [&](int iy, int (&r)[NC]) {
+            const bool rv = (unsigned)iy < (unsigned)H;
+            const int8_t *rowp = img + (size_t)min(max(iy, 0), H - 1) * W * C;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[p][j] = b4[j];
-        const int ncol = (DW_PX - 1) * 2 + 3;   // input columns a thread may touch (stride <= 2)
+            for (int c = 0; c < NC; ++c) r[c] = *reinterpret_cast<const int *>(rowp + coff[c]);
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int iy = oy * stride - 1 + kh;
-            if ((unsigned)iy >= (unsigned)H) continue;
-            const int8_t *rowp = in + ((size_t)n * H + iy) * W * C + 4 * cg;
+            for (int c = 0; c < NC; ++c) r[c] = (rv && ((cmask >> c) & 1)) ? r[c] : 0;
+        };
+        int r0[NC], r1[NC], r2[NC];
+        load_row(oy0 * S - 1, r0);
+        load_row(oy0 * S, r1);
+        for (int oy = oy0; oy < oy1; ++oy) {
+            load_row(oy * S + 1, r2);
+            int acc[DW_PX][4];
 #pragma unroll
-            for (int col = 0; col < ncol; ++col) {
-                if (stride == 1 && col >= DW_PX + 2) break;
-                const int ix = ox0 * stride - 1 + col;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const int xw = *reinterpret_cast<const int *>(rowp + (size_t)ix * C);
+            for (int p = 0; p < DW_PX; ++p)
 #pragma unroll
-                for (int p = 0; p < DW_PX; ++p) {
-                    const int kw = col - p * stride;    // tap of output p that reads this column
-                    if (kw < 0 || kw > 2) continue;
-                    const int ww = wreg[kh * 3 + kw];
+                for (int j = 0; j < 4; ++j) acc[p][j] = b4[j];
+            // sdot4 multiplies byte by byte: byte j of the masked weight meets byte j of the input, the other three products are 0
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[p][j] += (int)(int8_t)(xw >> (8 * j)) * (int)(int8_t)(ww >> (8 * j));
+            for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[p][j] = __builtin_amdgcn_sdot4(r0[p * S + kw], wm[kw][j], acc[p][j], false);
+                        acc[p][j] = __builtin_amdgcn_sdot4(r1[p * S + kw], wm[3 + kw][j], acc[p][j], false);
+                        acc[p][j] = __builtin_amdgcn_sdot4(r2[p * S + kw], wm[6 + kw][j], acc[p][j], false);
+                    }
+#pragma unroll
+            for (int p = 0; p < DW_PX; ++p)
+                if (ox0 + p < Wo) {
+                    const size_t o4 = (((size_t)n * Ho + oy) * Wo + ox0 + p) * C + 4 * cg;
+                    if (out) *reinterpret_cast<v4i *>(out + o4) = v4i{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+                    if constexpr (REQ) {
+                        int qv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) qv[j] = clampi(dyadic_rne(relu ? max(acc[p][j], 0) : acc[p][j], m4[j], e4[j]), q_lo, q_hi);
+                        *reinterpret_cast<uint32_t *>(out_q + o4) = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+                    }
+                }
+            if (oy + 1 < oy1) {
+                if constexpr (S == 1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r0[c] = r1[c], r1[c] = r2[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r0[c] = r2[c];
+                    load_row((oy + 1) * S, r1);
                 }
             }
         }
-        v4i m4 = {0, 0, 0, 0}, e4 = {0, 0, 0, 0};
-        if constexpr (REQ) m4 = *reinterpret_cast<const v4i *>(mult + 4 * cg), e4 = *reinterpret_cast<const v4i *>(expo + 4 * cg);
-#pragma unroll
-        for (int p = 0; p < DW_PX; ++p)
-            if (ox0 + p < Wo) {
-                const size_t o4 = (((size_t)n * Ho + oy) * Wo + ox0 + p) * C + 4 * cg;
-                if (out) *reinterpret_cast<v4i *>(out + o4) = v4i{acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
-                if constexpr (REQ) {
-                    int qv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) qv[j] = clampi(dyadic_rne(relu ? max(acc[p][j], 0) : acc[p][j], m4[j], e4[j]), q_lo, q_hi);
-                    *reinterpret_cast<uint32_t *>(out_q + o4) = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
-                }
-            }
     }
+}
+
+template <bool REQ>
+int depthwise_launch(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e, int N, int H, int W, int C, int stride,
+                     int relu, int q_lo, int q_hi, int8_t *out_q, int32_t *out_acc, void *stream) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3: empty output");
+    // rows per band: as tall as leaves ~4 waves per SIMD of the chip (2^18 threads), at most DW_MAX_BAND
+    const long long per_row = (long long)N * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
+    long long band = per_row * Ho / (1 << 18);
+    band = band < 1 ? 1 : (band > DW_MAX_BAND ? DW_MAX_BAND : band);
+    if (band > Ho) band = Ho;
+    const long long total = per_row * ((Ho + band - 1) / band);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    auto kern = stride == 1 ? depthwise3x3_kernel<REQ, 1> : depthwise3x3_kernel<REQ, 2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, Ho, Wo, (int)band, out_acc, m, e, relu, q_lo, q_hi,
+                       out_q);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 }  // namespace
 
@@ -293,14 +353,7 @@ extern "C" int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const in
                                  int32_t stride, int32_t *out_acc, void *stream) {
     HAWQ_REQUIRE(in && wgt9c && out_acc, "hawq_depthwise3x3: null pointer");
     HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3: empty output");
-    const long long total = (long long)N * Ho * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(depthwise3x3_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, stride, Ho, Wo, out_acc,
-                       nullptr, nullptr, 0, 0, 0, nullptr);
-    HAWQ_CHECK_HIP(hipGetLastError());
-    return 0;
+    return depthwise_launch<false>(in, wgt9c, bias, nullptr, nullptr, N, H, W, C, stride, 0, 0, 0, nullptr, out_acc, stream);
 }
 
 extern "C" int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e,
@@ -309,12 +362,65 @@ extern "C" int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, 
     HAWQ_REQUIRE(in && wgt9c && m && e && out_q, "hawq_depthwise3x3_requant: null pointer");
     HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3_requant: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
     HAWQ_REQUIRE(q_lo >= -128 && q_hi <= 127 && q_lo <= q_hi, "hawq_depthwise3x3_requant: the clamp must fit int8");
-    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3_requant: empty output");
-    const long long total = (long long)N * Ho * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(depthwise3x3_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, stride, Ho, Wo, out_acc,
-                       m, e, relu, q_lo, q_hi, out_q);
+    return depthwise_launch<true>(in, wgt9c, bias, m, e, N, H, W, C, stride, relu, q_lo, q_hi, out_q, out_acc, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input quantiser + im2col for a 3x3 / stride 2 / pad 1 first convolution on 3 input channels (MobileNetV2's init block,
+// q_mobilenetv2.py:110-113 after the input QuantAct, quant_modules.py:271-274): fp32 NCHW image in, one 64-byte int8 row per
+// OUTPUT pixel out, holding the 27 quantised patch values in (kh, kw, c) order and 37 zeros.  The 3x3 convolution on a
+// 3 -> 64 channel-padded tensor (9 x 64 bytes of K per output, 95 % of them padding) becomes a 1x1 convolution with K = 64
+// on a tensor a quarter of the size.  q = clamp(rne(fl(1/S) * x)), one binary32 rounding as `1. / scale * input` has.
+namespace {
+__global__ __launch_bounds__(256) void quantize_im2col3x3s2_kernel(const float *__restrict__ x, int8_t *__restrict__ out, int N, int H, int W, int Ho, int Wo,
+                                                                   float inv_scale, int lo, int hi) {
+    const long long total = (long long)N * Ho * Wo;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const long long r = i / Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        int q[28];
+        q[27] = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = 2 * oy - 1 + kh;
+            const bool rv = (unsigned)iy < (unsigned)H;
+            const int iyc = min(max(iy, 0), H - 1);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = 2 * ox - 1 + kw;
+                const bool ok = rv && (unsigned)ix < (unsigned)W;
+                const int ixc = min(max(ix, 0), W - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = x[(((long long)n * 3 + c) * H + iyc) * W + ixc];
+                    float rr = rintf(__fmul_rn(inv_scale, v));
+                    rr = fminf(fmaxf(rr, (float)lo), (float)hi);
+                    q[(kh * 3 + kw) * 3 + c] = ok ? (int)rr : 0;
+                }
+            }
+        }
+        v4i *dst = reinterpret_cast<v4i *>(out + i * 64);
+        v4i o0, o1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o0[k] = (int)pack4_i8(q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o1[k] = (int)pack4_i8(q[16 + 4 * k], q[17 + 4 * k], q[18 + 4 * k], q[19 + 4 * k]);
+        o1[3] = 0;
+        dst[0] = o0, dst[1] = o1, dst[2] = v4i{0, 0, 0, 0}, dst[3] = v4i{0, 0, 0, 0};
+    }
+}
+}  // namespace
+
+extern "C" int hawq_quantize_im2col3x3s2(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t q_lo,
+                                         int32_t q_hi, void *stream) {
+    HAWQ_REQUIRE(x && out, "hawq_quantize_im2col3x3s2: null pointer");
+    HAWQ_REQUIRE(C == 3, "hawq_quantize_im2col3x3s2: C=%d, the 64-byte patch row is laid out for 3 input channels", C);
+    HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && q_lo >= -128 && q_hi <= 127 && q_lo <= q_hi, "hawq_quantize_im2col3x3s2: bad geometry or range");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(quantize_im2col3x3s2_kernel, dim3(grid_for((long long)N * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, out, N, H, W, Ho, Wo,
+                       inv_scale, q_lo, q_hi);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

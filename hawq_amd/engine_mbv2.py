@@ -38,7 +38,7 @@ import torch
 
 from . import _lib, packing
 from .quant_modules import QuantAct, QuantBnConv2d
-from .quant_utils import quantize_weight_per_channel, requant_table
+from .quant_utils import quantize_weight_per_channel, requant_table, tables_are_fast, tables_fit_fast
 
 
 def _pad64(c: int) -> int:
@@ -63,18 +63,29 @@ def _padded(v, n, fill=0):
 class _Layer:
     """Device-resident integer parameters of one QuantBnConv2d, channel-padded."""
 
-    def __init__(self, mod: QuantBnConv2d, s_a, dev, from_buffers):
+    def __init__(self, mod: QuantBnConv2d, s_a, dev, from_buffers, im2col=False):
         if not from_buffers:
             mod.prepare(s_a)
         w = np.rint(mod.weight_integer.detach().cpu().numpy().astype(np.float64)).astype(np.int64)
-        self.cout, cg, self.kh, self.kw = w.shape
         self.stride, self.pad, self.groups = int(mod.conv.stride[0]), int(mod.conv.padding[0]), int(mod.conv.groups)
+        self.im2col = bool(im2col and w.shape[1:] == (3, 3, 3) and (self.stride, self.pad, self.groups) == (2, 1, 1))
+        if self.im2col:   # the input quantiser writes (kh, kw, c) patches (hawq_quantize_im2col3x3s2): a 1x1 conv on K = 27 -> 64
+            w = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], 27, 1, 1)
+            self.stride, self.pad = 1, 0
+        self.cout, cg, self.kh, self.kw = w.shape
         self.cin = cg * self.groups
         self.cin_p, self.cout_p = _pad64(self.cin), _pad64(self.cout)
         self.s_w = mod.convbn_scaling_factor.detach().float().cpu().reshape(-1)
         b = np.clip(np.rint(mod.bias_integer.detach().cpu().numpy().astype(np.float64)), -2 ** 31, 2 ** 31 - 1).astype(np.int64)
         self.bias = _i32(_padded(b, self.cout_p), dev)
+        self.b_host = b
+        # exact per-channel bound on |accumulator| -> bit length (8-bit activations), for the requant pre-shift check
+        bound = np.abs(w).reshape(self.cout, -1).sum(1) * 128 + np.abs(b)
+        self.vbits = np.array([int(v).bit_length() for v in bound], np.int64)
+        if (self.vbits > 31).any():
+            raise ValueError("int32 accumulator overflow is possible for this layer")
         self.w_host = w
+        self.weight_bytes = int(w.size) + 12 * self.cout   # int8 weights + bias / multiplier / exponent
         if self.groups == 1:
             self.w = torch.from_numpy(packing.pack_conv_weight(w, 8, self.cin_p, self.cout_p)).to(dev)
         elif self.groups == self.cin == self.cout and (self.kh, self.kw, self.pad) == (3, 3, 1):
@@ -151,10 +162,20 @@ class MobileNetV2Engine:
             lo, hi = _rng(act)
             if not _relu6_is_relu(float(s_a.item()), layer.s_w.numpy(), mh, eh, hi):
                 raise NotImplementedError("a QuantAct range above 6.0 behind ReLU6: the integer plan folds ReLU6 into the clamp")
-            return dict(m=md, e=ed, lo=max(lo, 0), hi=hi, s=s_o)
+            ent = dict(m=md, e=ed, lo=max(lo, 0), hi=hi, s=s_o)
+            if layer.groups == 1:
+                # the conv kernels' short requant (one v_mad_i64_i32 against a fused per-channel constant) where the lifted table
+                # fits its contract; bit 2 keeps exact round-half-even where a tie cannot be excluded on the host
+                mm, ee = requant_table(s_a, layer.s_w, s_o, vbits=layer.vbits)
+                if tables_fit_fast(mm, ee, layer.vbits):
+                    cp = layer.cout_p
+                    ent['ctab'] = _i32(packing.pack_ctab(_padded(layer.b_host, cp), _padded(mm, cp), _padded(ee, cp, 33)), dev)
+                    ent['m'], ent['e'] = _i32(_padded(mm, cp), dev), _i32(_padded(ee, cp, 33), dev)
+                    ent['fast'] = 1 if tables_are_fast(mm, ee, layer.vbits) else 5
+            return ent
 
         # init block: conv -> ReLU6 -> quant_act_int32 (16 bit)
-        init = _Layer(m.init_block, s_in, dev, self.from_buffers)
+        init = _Layer(m.init_block, s_in, dev, self.from_buffers, im2col=True)
         s16 = act16(m.quant_act_int32)
         md, ed, mh, eh = init.table(s_in, s16, dev)
         if not _relu6_is_relu(float(s_in.item()), init.s_w.numpy(), mh, eh, 32767):
@@ -234,6 +255,7 @@ class MobileNetV2Engine:
         r = _lib.ConvArgs()
         C.memmove(C.byref(r), C.byref(a), C.sizeof(r))
         r.epilogue, r.out_acc, r.res_in, r.res_out, r.out_q = _lib.EPI_RAW, acc.data_ptr(), None, None, None
+        r.fast_tables, r.ctab = 0, None
         keep += [acc, r]
         self.taps[name] = (acc, (N, ho, wo, cout_p), cout)
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
@@ -243,23 +265,37 @@ class MobileNetV2Engine:
         if self._graph is not None:
             _lib.call("hawq_graph_destroy", self._graph)
         ops, keep, self.taps, self._graph = [], [], {}, None
+        self.n_fast = 0
+        self.plan_bytes = N * 3 * H * W * 4   # bytes the plan has to move at the networks' true widths (no padding channels)
         alloc = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
         self.x_in = alloc(N * 3 * H * W, torch.float32).view(N, 3, H, W)
-        xq_f = alloc(N * 3 * H * W, torch.float32)
         init = P['init']['layer']
-        xq = torch.zeros(N * H * W * init.cin_p, dtype=torch.int8, device=dev)
-        # input QuantAct (quant_modules.py:271-274) then int8 NHWC, channels padded to 64
-        ops.append(partial(_lib.call, "hawq_fakequant_f32", self.x_in.data_ptr(), xq_f.data_ptr(), N * 3 * H * W, P['inv_s_in'], P['s_in'], -128, 127, sp))
-        ops.append(partial(_lib.call, "hawq_f32_nchw_to_q_nhwc", xq_f.data_ptr(), xq.data_ptr(), N, 3, H, W, init.cin_p, 8, P['s_in'], sp))
-        keep += [xq_f, xq]
+        if init.im2col:
+            # input QuantAct (quant_modules.py:271-274) straight into the init conv's 27-value patches, one 64-byte row per output pixel
+            H0, W0 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            xq = alloc(N * H0 * W0 * 64, torch.int8)
+            ops.append(partial(_lib.call, "hawq_quantize_im2col3x3s2", self.x_in.data_ptr(), xq.data_ptr(), N, 3, H, W, P['inv_s_in'], -128, 127, sp))
+            keep.append(xq)
+        else:
+            # input QuantAct then int8 NHWC, channels padded to 64
+            H0, W0 = H, W
+            xq_f = alloc(N * 3 * H * W, torch.float32)
+            xq = torch.zeros(N * H * W * init.cin_p, dtype=torch.int8, device=dev)
+            ops.append(partial(_lib.call, "hawq_fakequant_f32", self.x_in.data_ptr(), xq_f.data_ptr(), N * 3 * H * W, P['inv_s_in'], P['s_in'], -128, 127, sp))
+            ops.append(partial(_lib.call, "hawq_f32_nchw_to_q_nhwc", xq_f.data_ptr(), xq.data_ptr(), N, 3, H, W, init.cin_p, 8, P['s_in'], sp))
+            keep += [xq_f, xq]
 
-        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name):
-            """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo)"""
+        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True):
+            """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo);
+            the 32-bit carrier is only written where something reads it (the next unit's identity, the pool, a tap)"""
             ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
             a = self._conv_args(L, x, n, h, w)
             a.epilogue, a.m, a.e = _lib.EPI_RESIDUAL, m.data_ptr(), e.data_ptr()
-            out16 = alloc(n * ho * wo * L.cout_p, torch.int32)
-            a.res_out, a.res_out_bits = out16.data_ptr(), 32
+            out16 = None
+            if need16 or self.keep_acc:
+                out16 = alloc(n * ho * wo * L.cout_p, torch.int32)
+                a.res_out, a.res_out_bits = out16.data_ptr(), 32
+            self.plan_bytes += n * (h * w * L.cin + ho * wo * L.cout * ((4 if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
             if res_in is not None:
                 a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = res_in.data_ptr(), 32, m_id, e_id
             a.res_no_relu, a.res_clamp16 = int(not relu), int(clamp16)
@@ -271,15 +307,16 @@ class MobileNetV2Engine:
                 self._tap(ops, keep, name, a, n, ho, wo, L.cout, L.cout_p)
             keep.extend([a, out16, q])
             ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
-            self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_p), L.cout)
+            if out16 is not None:
+                self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_p), L.cout)
             if q is not None:
                 self.taps[name + ":next_q"] = (q, (n, ho, wo, L.cout_p), L.cout)
             return out16, q, ho, wo
 
         units = P['units']
         u0 = units[0]
-        x16, q, h, w = closing(init, P['init']['m'], P['init']['e'], xq, N, H, W, None, 0, 33, True, True,
-                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block")
+        x16, q, h, w = closing(init, P['init']['m'], P['init']['e'], xq, N, H0, W0, None, 0, 33, True, True,
+                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block", need16=u0['residual'])
         for ui, u in enumerate(units):
             name = f"unit{ui + 1}"
             x = q
@@ -292,6 +329,9 @@ class MobileNetV2Engine:
                     a = self._conv_args(L, x, N, h, w)
                     a.epilogue, a.relu, a.m, a.e = _lib.EPI_REQUANT, 1, ent['m'].data_ptr(), ent['e'].data_ptr()
                     a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), 8, ent['lo'], ent['hi']
+                    if ent.get('fast'):
+                        a.fast_tables, a.ctab = ent['fast'], ent['ctab'].data_ptr()
+                        self.n_fast += 1
                     if self.keep_acc:
                         self._tap(ops, keep, lname, a, N, ho, wo, L.cout, L.cout_p)
                     keep.append(a)
@@ -304,6 +344,7 @@ class MobileNetV2Engine:
                                        ent['e'].data_ptr(), N, h, w, L.cout_p, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
                                        None if acc is None else acc.data_ptr(), sp))
                     keep.append(acc)
+                self.plan_bytes += N * (h * w * L.cin + ho * wo * L.cout) + L.weight_bytes
                 self.taps[lname + ":q"] = (out, (N, ho, wo, L.cout_p), L.cout)
                 keep.append(out)
                 x, h, w = out, ho, wo
@@ -311,7 +352,7 @@ class MobileNetV2Engine:
             nq = (nxt['mq'], nxt['eq'], nxt['q_rng']) if nxt is not None else (P['before_final']['mq'], P['before_final']['eq'], P['before_final']['rng'])
             pr = u['proj']
             x16, q, h, w = closing(pr['layer'], pr['m'], pr['e'], x, N, h, w, x16 if u['residual'] else None, u.get('m_id', 0), u.get('e_id', 33),
-                                   False, not u['residual'], nq, name + ".conv3")
+                                   False, not u['residual'], nq, name + ".conv3", need16=bool(nxt is not None and nxt['residual']))
         fin = P['final']
         x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block")
         cl = fin['layer'].cout_p

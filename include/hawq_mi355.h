@@ -262,6 +262,13 @@ int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32
                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu, int32_t q_lo, int32_t q_hi,
                               int8_t *out_q, int32_t *out_acc, void *stream);
 
+/* Input QuantAct + im2col for a 3x3 / stride 2 / pad 1 first conv on 3 channels (MobileNetV2's init block, q_mobilenetv2.py:110-113
+ * after quant_modules.py:271-274): x fp32 [N][3][H][W] -> out int8 [N][Ho][Wo][64], row = the 27 values
+ * clamp(rne(inv_scale * x), q_lo, q_hi) of the output pixel's patch in (kh, kw, c) order (zero outside the image), then 37 zeros.
+ * The conv then runs as a 1x1 hawq_conv2d with Cin = 64 on weights laid out in the same (kh, kw, c) order.  C must be 3. */
+int hawq_quantize_im2col3x3s2(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t q_lo,
+                              int32_t q_hi, void *stream);
+
 /* One separable pass of Pillow's 8-bit antialiased resampling (what torchvision's Resize(256) does to the decoded PIL image,
  * quant_train.py:428-440): uint8 HWC in / out, int32 coefficients with 22 fractional bits (hawq_amd/image.py builds them as
  * Resample.c's precompute_coeffs + normalize_coeffs_8bpc do).

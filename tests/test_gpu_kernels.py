@@ -796,6 +796,45 @@ def test_residual_epilogue_without_relu_and_with_the_16_bit_clamp(lib, orc, mode
     assert lib.load().hawq_conv2d(C.byref(a), None) != 0
 
 
+@pytest.mark.parametrize("hw", [(8, 8), (9, 7), (33, 46), (224, 224)])
+def test_quantize_im2col_is_the_input_quantiser_plus_patch_gather(lib, orc, hw):
+    """hawq_quantize_im2col3x3s2 (MobileNetV2's input QuantAct fused with the im2col of its 3x3 / stride 2 / pad 1 init conv):
+    every 64-byte row = the oracle-quantised 27 patch values in (kh, kw, c) order + zeros; a 1x1 conv on those rows with the
+    weights in the same order equals the oracle's 3x3 stride-2 convolution of the quantised image."""
+    h, w = hw
+    n = 2
+    rng = np.random.default_rng(h * 31 + w)
+    x = rng.normal(0, 1.1, (n, 3, h, w)).astype(f32)
+    x.reshape(-1)[:6] = [0.5, 1.5, 2.5, -0.5, 1e9, -1e9]
+    scale = f32(0.0173)
+    q = orc.quantize_f32(x, scale, 8)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    out = torch.full((n * ho * wo * 64,), 55, dtype=torch.int8, device='cuda')
+    xd = dev(x)
+    lib.call("hawq_quantize_im2col3x3s2", xd.data_ptr(), out.data_ptr(), n, 3, h, w, float(f32(1) / scale), -128, 127, stream())
+    got = out.cpu().numpy().reshape(n, ho, wo, 64).astype(np.int64)
+    qp = np.pad(q, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    ref = np.zeros((n, ho, wo, 64), np.int64)
+    for kh in range(3):
+        for kw in range(3):
+            for c in range(3):
+                ref[..., (kh * 3 + kw) * 3 + c] = qp[:, c, kh:kh + 2 * (ho - 1) + 1:2, kw:kw + 2 * (wo - 1) + 1:2]
+    assert np.array_equal(got, ref)
+    if h <= 64:
+        wt = rng.integers(-127, 128, (64, 3, 3, 3)).astype(np.int64)
+        b = rng.integers(-1000, 1000, 64).astype(np.int64)
+        acc = orc.conv2d(q, wt, b, 2, 1)
+        w27 = np.zeros((64, 64, 1, 1), np.int64)
+        w27[:, :27, 0, 0] = wt.transpose(0, 2, 3, 1).reshape(64, 27)
+        a, keep = conv_args(lib, ref.transpose(0, 3, 1, 2), w27, b, 1, 0, 8, 8)
+        a.in_ = out.data_ptr()
+        o = torch.zeros(n * ho * wo * 64, dtype=torch.int32, device='cuda')
+        a.epilogue, a.out_acc = lib.EPI_RAW, o.data_ptr()
+        lib.call("hawq_conv2d", C.byref(a), stream())
+        assert np.array_equal(o.cpu().numpy().reshape(n, ho, wo, 64).transpose(0, 3, 1, 2), acc)
+    assert lib.load().hawq_quantize_im2col3x3s2(xd.data_ptr(), out.data_ptr(), n, 4, h, w, 1.0, -128, 127, None) != 0
+
+
 def test_range_statistics_kernels_match_reference_kats(lib):
     """hawq_minmax_f32 / hawq_kthvalue_f32 behind get_percentile_min_max and the un-frozen QuantAct (min/max and
     percentile ranges, initialisation + momentum / running-extremum updates) against the live reference's numbers."""
