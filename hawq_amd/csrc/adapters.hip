@@ -368,7 +368,7 @@ extern "C" int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, 
 
 // ------------------------------------------------------------------------------------------------------------------
 // Input quantiser + im2col for a 3x3 / stride 2 / pad 1 first convolution on 3 input channels (MobileNetV2's init block,
-// q_mobilenetv2.py:110-113 after the input QuantAct, quant_modules.py:271-274): fp32 NCHW image in, one 64-byte int8 row per
+// q_mobilenetv2.py:182-186 after the input QuantAct, quant_modules.py:271-274): fp32 NCHW image in, one 64-byte int8 row per
 // OUTPUT pixel out, holding the 27 quantised patch values in (kh, kw, c) order and 37 zeros.  The 3x3 convolution on a
 // 3 -> 64 channel-padded tensor (9 x 64 bytes of K per output, 95 % of them padding) becomes a 1x1 convolution with K = 64
 // on a tensor a quarter of the size.  q = clamp(rne(fl(1/S) * x)), one binary32 rounding as `1. / scale * input` has.

@@ -530,7 +530,7 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
                         for (int j = 0; j < 4; ++j) {
                             o[j] = dyadic_rne(v[j], mm[j], ee[j]) + idv[j];          // no clamp with an identity: quant_utils.py:456
                             if (!p.res_no_relu) o[j] = max(o[j], 0);
-                            if (p.res_clamp16) o[j] = clampi(o[j], -32768, 32767);   // case 0 clamps to its 16-bit range (:409-413)
+                            if (p.res_clamp16) o[j] = clampi(o[j], -32768, 32767);   // case 0 clamps to its 16-bit range (quant_utils.py:409-413)
                             qv[j] = clampi(dyadic_rne(o[j], p.mq, p.eq), p.q_lo, p.q_hi);
                             ovf |= o[j] > 65535;
                         }

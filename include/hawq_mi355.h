@@ -254,7 +254,7 @@ int hawq_conv2d_grouped(const int8_t *in, const int8_t *wgt, const int32_t *bias
 int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, int32_t N, int32_t H, int32_t W, int32_t C,
                       int32_t stride, int32_t *out_acc, void *stream);
 
-/* The same with the conv's activation + QuantAct fused (conv2 -> ReLU6 -> quant_act2 of a MobileNetV2 unit, q_mobilenetv2.py:71-73;
+/* The same with the conv's activation + QuantAct fused (conv2 -> ReLU6 -> quant_act2 of a MobileNetV2 unit, q_mobilenetv2.py:70-72;
  * ReLU6 == ReLU + the QuantAct's own clamp: its calibrated range never exceeds 6): out_q[N][Ho][Wo][C] int8 =
  * clamp(dyadic_rne(relu ? max(acc + bias, 0) : acc + bias, m[c], e[c]), q_lo, q_hi) with exact (tie-aware) rounding;
  * out_acc (optional) additionally receives the int32 accumulators. */
@@ -262,7 +262,7 @@ int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32
                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu, int32_t q_lo, int32_t q_hi,
                               int8_t *out_q, int32_t *out_acc, void *stream);
 
-/* Input QuantAct + im2col for a 3x3 / stride 2 / pad 1 first conv on 3 channels (MobileNetV2's init block, q_mobilenetv2.py:110-113
+/* Input QuantAct + im2col for a 3x3 / stride 2 / pad 1 first conv on 3 channels (MobileNetV2's init block, q_mobilenetv2.py:182-186
  * after quant_modules.py:271-274): x fp32 [N][3][H][W] -> out int8 [N][Ho][Wo][64], row = the 27 values
  * clamp(rne(inv_scale * x), q_lo, q_hi) of the output pixel's patch in (kh, kw, c) order (zero outside the image), then 37 zeros.
  * The conv then runs as a 1x1 hawq_conv2d with Cin = 64 on weights laid out in the same (kh, kw, c) order.  C must be 3. */

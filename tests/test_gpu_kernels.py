@@ -753,7 +753,7 @@ def test_residual_epilogue_without_relu_and_with_the_16_bit_clamp(lib, orc, mode
     """The general RESIDUAL epilogue's MobileNetV2 switches (hawq_conv_args.res_no_relu / res_clamp16 / res_in == NULL):
     a linear bottleneck ends without an activation, so the 32-bit carrier holds signed values - requant(acc) [+ identity],
     clamped to the signed 16-bit range only where the reference's QuantAct runs fixedpoint_fn case 0
-    (quant_modules.py:239-262), then requantised for the next unit with a signed clamp."""
+    (quant_utils.py:390-413), then requantised for the next unit with a signed clamp."""
     from hawq_amd.quant_utils import requant_table
     rng = np.random.default_rng(len(mode))
     n, h, w, cin, cout = 2, 9, 7, 64, 128
