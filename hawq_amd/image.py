@@ -5,9 +5,13 @@ the look-up table of ``IntegerEngine.forward_uint8``.
 torchvision's Resize on a PIL image is ``Image.resize(..., BILINEAR)``: Pillow's antialiased separable resampling
 (libImaging/Resample.c).  The coefficient construction below restates its ``precompute_coeffs`` (binary64, support scaled by
 the down-sampling factor, taps normalised to sum 1) and ``normalize_coeffs_8bpc`` (22 fractional bits, round half away);
-the two passes run in ``hawq_resample_u8``.  Pillow itself is not installable in the build container, so this stage is
-**parity-unpinned**: it is tested against ``oracle/pil_resample.py``, a numpy restatement of the same published algorithm,
-not against Pillow's output.  JPEG decoding stays on the host (any decoder that yields uint8 HWC).
+the two passes run in ``hawq_resample_u8``.  Pinned to REAL Pillow output: ``tests/golden/pillow_resize.npz``
+(``make_pillow.py``, Pillow 12.2) holds what ``Image.resize(..., BILINEAR)`` + the crop produce for nine geometries and a JPEG;
+``oracle/pil_resample.py`` and this device stage both reproduce it bit for bit.
+
+JPEG decoding stays on the host, as in the reference (``datasets.ImageFolder``'s ``pil_loader`` inside DataLoader workers,
+quant_train.py:428-445): ``decode_image`` / ``folder_loader`` below use Pillow when it is installed and say so when it is not;
+everything after the decoded uint8 HWC pixels runs on the MI355X.
 """
 from __future__ import annotations
 
@@ -98,3 +102,47 @@ def resize_center_crop(img: torch.Tensor, resize: int = 256, crop: int = 224) ->
 def preprocess_batch(images, resize: int = 256, crop: int = 224) -> torch.Tensor:
     """List of decoded uint8 HWC images (any sizes, host or device) -> uint8 [N, crop, crop, C] for ``forward_uint8``."""
     return torch.stack([resize_center_crop(im.cuda() if not im.is_cuda else im, resize, crop) for im in images])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Host side of the data path (quant_train.py:428-445): the files of an ImageFolder tree, decoded as its pil_loader does
+IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+
+
+def decode_image(source) -> torch.Tensor:
+    """File path, bytes or file object -> uint8 HWC RGB tensor (host), decoded as torchvision's ``pil_loader`` does
+    (``Image.open(f).convert('RGB')``).  Needs Pillow - the decoder is not part of the integer hot path."""
+    try:
+        from PIL import Image
+    except ImportError as e:   # pragma: no cover - the build container has Pillow
+        raise RuntimeError("hawq_amd.image.decode_image needs Pillow; pass decoded uint8 HWC tensors to preprocess_batch instead") from e
+    import io
+    if isinstance(source, (bytes, bytearray, memoryview)):
+        source = io.BytesIO(bytes(source))
+    with Image.open(source) as im:
+        arr = np.array(im.convert("RGB"))   # a copy: Pillow's buffer is read-only
+    return torch.from_numpy(arr)
+
+
+def image_folder(root: str):
+    """(path, class index) pairs of an ImageFolder tree: class = sub-directory, indices by sorted directory name, files in
+    sorted walk order (torchvision.datasets.folder.make_dataset)."""
+    import os
+    classes = sorted(d.name for d in os.scandir(root) if d.is_dir())
+    if not classes:
+        raise FileNotFoundError(f"no class directories under {root}")
+    samples = []
+    for idx, c in enumerate(classes):
+        for dirpath, _, files in sorted(os.walk(os.path.join(root, c), followlinks=True)):
+            samples += [(os.path.join(dirpath, f), idx) for f in sorted(files) if f.lower().endswith(IMG_EXTENSIONS)]
+    return samples, classes
+
+
+def folder_loader(root: str, batch_size: int = 128, resize: int = 256, crop: int = 224, device="cuda"):
+    """Iterate an ImageFolder tree as ``(uint8 [n, crop, crop, 3] on the MI355X, int64 targets)`` batches - the validation loader of
+    quant_train.py:428-445 (shuffle off) with everything behind the decoder on the device; feed it to ``api.validate(uint8=True)``."""
+    samples, _ = image_folder(root)
+    for i in range(0, len(samples), batch_size):
+        part = samples[i:i + batch_size]
+        imgs = [decode_image(p).to(device) for p, _ in part]
+        yield preprocess_batch(imgs, resize, crop), torch.tensor([t for _, t in part], dtype=torch.int64)

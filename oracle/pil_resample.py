@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY - numpy restatement of Pillow's 8-bit antialiased bilinear resize (libImaging/Resample.c:
 precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc, ImagingResampleVertical_8bpc) as
 ``Image.resize(size, BILINEAR)`` runs it - what torchvision's Resize(256) does to a PIL image (quant_train.py:428-440).
-PARITY UNPINNED: Pillow is absent from the build container and the reference ships no resized fixtures, so this file is
-checked against nothing but itself; the HIP path (hawq_amd/image.py) is tested against it.  Independent of hawq_amd: its
-own coefficient code, whole-image passes, then the crop."""
+PINNED to real Pillow: tests/golden/pillow_resize.npz holds the output of Pillow 12.2 itself (tests/golden/make_pillow.py, nine
+geometries + a decoded JPEG); tests/test_host_logic.py requires this file to reproduce every byte of it, and - where Pillow is
+installed - compares live on further random geometries.  The HIP path (hawq_amd/image.py) is tested against the same fixture.
+Independent of hawq_amd: its own coefficient code, whole-image passes, then the crop."""
 import math
 
 import numpy as np

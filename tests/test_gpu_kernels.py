@@ -2,6 +2,7 @@
 Bit-exact: every comparison is np.array_equal on integers (or on fp32 produced by one exact
 multiply)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -870,6 +871,40 @@ def test_range_statistics_kernels_match_reference_kats(lib):
             got = np.array([float(a.x_min), float(a.x_max), float(s)], np.float32)
             assert np.array_equal(got, kx[f"act_{tag}_rng"][it]), (tag, it, got, kx[f"act_{tag}_rng"][it])
             assert np.array_equal(y.cpu().numpy(), kx[f"act_{tag}_y"][it]), (tag, it)
+
+
+def test_device_resize_center_crop_reproduces_real_pillow_output(tmp_path):
+    """hawq_amd.image.resize_center_crop (hawq_resample_u8) against REAL Pillow: the crops tests/golden/make_pillow.py recorded from
+    `Image.resize(.., BILINEAR)` + CenterCrop(224) for nine geometries and a decoded JPEG, byte for byte.  With Pillow installed: the
+    committed JPEG through decode_image -> device pipeline, and an ImageFolder tree through folder_loader (classes / order / batches)."""
+    from hawq_amd.image import decode_image, folder_loader, resize_center_crop
+    from tests.test_host_logic import _synth_image
+    fx = H.load("pillow_resize.npz")
+    for i, (h, w) in enumerate(fx["geoms"]):
+        img = _synth_image(int(h), int(w), int(fx["seeds"][i]))
+        got = resize_center_crop(torch.from_numpy(img).cuda()).cpu().numpy()
+        assert np.array_equal(got, fx[f"crop_{i}"]), (h, w, int(np.abs(got.astype(int) - fx[f"crop_{i}"].astype(int)).max()))
+    got = resize_center_crop(torch.from_numpy(fx["jpeg_decoded"]).cuda()).cpu().numpy()
+    assert np.array_equal(got, fx["jpeg_crop"])
+    pytest.importorskip("PIL")
+    from PIL import Image
+    jpg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_500x375.jpg")
+    dec = decode_image(jpg)
+    ref = np.asarray(Image.open(jpg).convert("RGB").resize((341, 256), Image.BILINEAR))[16:240, 58:282]
+    assert np.array_equal(resize_center_crop(dec.cuda()).cpu().numpy(), ref)
+    rng = np.random.default_rng(2)
+    want = {}
+    for c in ("n01", "n02"):
+        (tmp_path / c).mkdir()
+        for k in range(3):
+            h, w = (int(v) for v in rng.integers(230, 420, 2))
+            Image.fromarray(_synth_image(h, w, k)).save(tmp_path / c / f"im{k}.jpg", quality=92)
+    batches = list(folder_loader(str(tmp_path), batch_size=4))
+    assert [tuple(b[0].shape) for b in batches] == [(4, 224, 224, 3), (2, 224, 224, 3)]
+    assert torch.cat([b[1] for b in batches]).tolist() == [0, 0, 0, 1, 1, 1]
+    first = np.asarray(Image.open(tmp_path / "n01" / "im0.jpg").convert("RGB"))
+    from oracle import pil_resample
+    assert np.array_equal(batches[0][0][0].cpu().numpy(), pil_resample.resize_center_crop(first))
 
 
 def test_resize_center_crop_matches_the_restated_pillow_algorithm():

@@ -172,6 +172,55 @@ def test_validate_loop_fp32_and_uint8():
     assert validate(model, u8, uint8=True) == (50.0, 50.0, 10)   # the rebuilt engine must re-upload its table
 
 
+def test_validate_from_a_jpeg_folder_equals_the_reference_pipeline_on_pillow(tmp_path):
+    """The validation data path of quant_train.py:428-445 end to end: an ImageFolder tree of JPEGs -> pil_loader decode (host, as in
+    the reference's DataLoader workers) -> Resize(256) + CenterCrop(224) + ToTensor + Normalize + input QuantAct on the MI355X
+    (folder_loader -> validate(uint8=True)) against the same images put through PILLOW's own resize / crop and the fp32 tensor
+    path: identical logits, hence identical accuracy counts.  Needs Pillow (skipped where it is not installed)."""
+    pytest.importorskip("PIL")
+    from PIL import Image
+    from hawq_amd.api import calibrate, validate
+    from hawq_amd.image import folder_loader
+    model = H.build_model("resnet18", "uniform8")
+    calibrate(model, _images().cuda())
+    rng = np.random.default_rng(4)
+    for c in ("a", "b", "c"):
+        (tmp_path / c).mkdir()
+        for k in range(3):
+            h, w = (int(v) for v in rng.integers(240, 520, 2))
+            yy, xx = np.mgrid[0:h, 0:w]
+            pic = np.stack([(xx * 3 + k * 40) % 256, (yy * 2 + xx) % 256, rng.integers(0, 256, (h, w))], -1).astype(np.uint8)
+            Image.fromarray(pic).save(tmp_path / c / f"{k}.jpg", quality=95)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    ref_logits, paths = [], []
+    for c in ("a", "b", "c"):
+        for k in range(3):
+            im = Image.open(tmp_path / c / f"{k}.jpg").convert("RGB")
+            w, h = im.size
+            ow, oh = (256, int(256 * h / w)) if w <= h else (int(256 * w / h), 256)
+            im = im.resize((ow, oh), Image.BILINEAR)
+            top, left = int(round((oh - 224) / 2.0)), int(round((ow - 224) / 2.0))
+            a = np.asarray(im)[top:top + 224, left:left + 224]
+            t = torch.from_numpy(a.copy()).permute(2, 0, 1).unsqueeze(0).to(torch.float32).div(255)
+            t = t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))
+            ref_logits.append(model(t.cuda()).cpu())
+    ref_logits = torch.cat(ref_logits)
+    got = torch.cat([model.engine().forward_uint8(b, mean, std).cpu() for b, _ in folder_loader(str(tmp_path), batch_size=4)])
+    assert torch.equal(got, ref_logits)
+    # labels := the reference pipeline's top-1 for class-a files, something else for the rest -> accuracy is known
+    pred = ref_logits.argmax(1)
+    class Loader:   # folder_loader's batches with the labels swapped for checkable ones
+        def __iter__(self):
+            i = 0
+            for b, t in folder_loader(str(tmp_path), batch_size=4):
+                lab = pred[i:i + len(t)].clone()
+                lab[t != 0] = ref_logits[i:i + len(t)].argmin(1)[t != 0]
+                i += len(t)
+                yield b, lab
+    t1, t5, n = validate(model, Loader(), uint8=True)
+    assert n == 9 and abs(t1 - 100.0 * 3 / 9) < 1e-9 and abs(t5 - 100.0 * 3 / 9) < 1e-9
+
+
 def test_concurrent_sub_batches_are_bit_identical():
     """The engine may split a batch into 2-3 sub-batches that run concurrently inside one hipGraph (chosen by
     timing at batch >= 48, or forced): logits must not depend on the split (uneven splits included)."""

@@ -286,13 +286,73 @@ def test_mobilenetv2_graph_and_schedules_line_up():
         assert mods["features.stage4.unit5.conv2"].weight_bit == cfg["features.stage4.unit5.conv2"]
 
 
+def _synth_image(h, w, seed):
+    """the picture tests/golden/make_pillow.py resized (kept in step with its synth())"""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    img[::7, ::5] = 255
+    img[3::11, 2::13] = 0
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[h // 3: 2 * h // 3, :, 1] = ((yy[h // 3: 2 * h // 3] * 3 + xx[h // 3: 2 * h // 3] * 2) % 256).astype(np.uint8)
+    return img
+
+
+def test_resize_restatement_reproduces_real_pillow_output():
+    """oracle/pil_resample.py against REAL Pillow (tests/golden/pillow_resize.npz, written by make_pillow.py with Pillow 12.2 in the
+    build container: `Image.resize(.., BILINEAR)` as torchvision's Resize(256) calls it, then CenterCrop(224),
+    quant_train.py:428-440): the whole resized image (SHA-256) and the crop, byte for byte, for nine geometries and the decoded
+    JPEG.  Where Pillow is installed the comparison is repeated live on further random geometries and the committed JPEG is decoded
+    again (pil_loader: `Image.open(f).convert('RGB')`)."""
+    import hashlib
+    from oracle import pil_resample as P
+    fx = H.load("pillow_resize.npz")
+    for i, (h, w) in enumerate(fx["geoms"]):
+        img = _synth_image(int(h), int(w), int(fx["seeds"][i]))
+        oh, ow = (int(v) for v in fx[f"full_shape_{i}"])
+        full = P.resize(img, oh, ow)
+        assert hashlib.sha256(full.tobytes()).hexdigest() == str(fx[f"full_sha_{i}"]), (h, w)
+        assert np.array_equal(P.resize_center_crop(img), fx[f"crop_{i}"]), (h, w)
+    assert np.array_equal(P.resize_center_crop(fx["jpeg_decoded"]), fx["jpeg_crop"])
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        h, w = (int(v) for v in rng.integers(40, 900, 2))
+        img = _synth_image(h, w, int(rng.integers(1 << 30)))
+        oh, ow = (int(256 * h / w), 256) if w <= h else (256, int(256 * w / h))
+        assert np.array_equal(P.resize(img, oh, ow), np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))), (h, w)
+    from hawq_amd.image import decode_image
+    dec = decode_image(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_500x375.jpg")).numpy()
+    assert dec.shape == (375, 500, 3) and dec.dtype == np.uint8
+    if PIL.__version__ == str(fx["pillow_version"]):   # another libjpeg build may round its IDCT differently
+        assert hashlib.sha256(dec.tobytes()).hexdigest() == str(fx["jpeg_decoded_sha"])
+    else:
+        assert np.abs(dec.astype(int) - fx["jpeg_decoded"].astype(int)).max() <= 2
+
+
+def test_image_folder_walk_matches_torchvisions_ordering(tmp_path):
+    """hawq_amd.image.image_folder: classes = sorted sub-directories, samples in sorted walk order, non-image files skipped
+    (torchvision.datasets.folder.make_dataset, which quant_train.py:428 uses through datasets.ImageFolder)."""
+    from hawq_amd.image import image_folder
+    for c, names in (("n02", ["b.JPEG", "a.jpg", "notes.txt"]), ("n01", ["z.png", "sub/k.jpeg"])):
+        for n in names:
+            f = tmp_path / c / n
+            f.parent.mkdir(parents=True, exist_ok=True)
+            f.write_bytes(b"x")
+    samples, classes = image_folder(str(tmp_path))
+    assert classes == ["n01", "n02"]
+    rel = [(os.path.relpath(p, tmp_path), t) for p, t in samples]
+    assert rel == [("n01/z.png", 0), ("n01/sub/k.jpeg", 0), ("n02/a.jpg", 1), ("n02/b.JPEG", 1)]
+    with pytest.raises(FileNotFoundError):
+        image_folder(str(tmp_path / "n01" / "sub"))
+
+
 def test_resize_restatement_agrees_with_torchs_uint8_antialias_bilinear_within_one_lsb():
     """oracle/pil_resample.py (the checker of the device Resize stage, written by the builder) against an implementation the builder
     did NOT write: torch-CPU `F.interpolate(uint8, mode="bilinear", antialias=True)`, PyTorch's port of Pillow-SIMD's resampling
     (what torchvision's Resize runs on uint8 tensors).  torch quantises its filter weights to fewer fractional bits than
     Pillow's 22, so the two are not bit-identical by construction (torchvision documents +-1 against PIL); what is pinned here:
-    never more than ONE level apart and equal in > 99.5 % of the elements.
-    Parity with Pillow's own output stays unpinned (Pillow is absent from the image) - stated in DESIGN.md 8."""
+    never more than ONE level apart and equal in > 99.5 % of the elements.  (The pin to Pillow's own output is the next test.)"""
     import torch
     import torch.nn.functional as F
     from oracle import pil_resample as P
