@@ -241,15 +241,17 @@ constexpr int DW_MAX_BAND = 8;
 // REQ: conv2 -> ReLU -> QuantAct fused (exact dyadic_rne per channel table), int8 out; `out` (int32) then optional
 template <bool REQ, int S>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ w9c, const int32_t *__restrict__ bias,
-                                                           int N, int H, int W, int C, int Ho, int Wo, int band, int32_t *__restrict__ out,
+                                                           int N, int H, int W, int C, int Cv, int Ho, int Wo, int band, int32_t *__restrict__ out,
                                                            const int32_t *__restrict__ mult, const int32_t *__restrict__ expo, int relu, int q_lo, int q_hi,
                                                            int8_t *__restrict__ out_q) {
     constexpr int NC = (DW_PX - 1) * S + 3;   // input columns under DW_PX outputs
-    const int cgs = C >> 2, wq = (Wo + DW_PX - 1) / DW_PX, bands = (Ho + band - 1) / band;
-    const long long total = (long long)N * bands * wq * cgs;
+    // Cv <= C: channels >= Cv are padding (zero weights / bias / multipliers): only the ceil(Cv / 4) real groups are computed,
+    // each thread also writes the zeros of the padding groups cg + i * cgv of its pixels
+    const int cgs = C >> 2, cgv = (Cv + 3) >> 2, wq = (Wo + DW_PX - 1) / DW_PX, bands = (Ho + band - 1) / band;
+    const long long total = (long long)N * bands * wq * cgv;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int cg = (int)(idx % cgs);
-        long long rest = idx / cgs;
+        const int cg = (int)(idx % cgv);
+        long long rest = idx / cgv;
         const int xq = (int)(rest % wq);
         rest /= wq;
         const int bi = (int)(rest % bands), n = (int)(rest / bands), ox0 = xq * DW_PX;
@@ -314,6 +316,11 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restr
                         for (int j = 0; j < 4; ++j) qv[j] = clampi(dyadic_rne(relu ? max(acc[p][j], 0) : acc[p][j], m4[j], e4[j]), q_lo, q_hi);
                         *reinterpret_cast<uint32_t *>(out_q + o4) = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
                     }
+                    for (int pc = cgv + cg; pc < cgs; pc += cgv) {   // padding groups: rne(0 * 0) = 0
+                        const size_t z4 = o4 + 4 * (size_t)(pc - cg);
+                        if (out) *reinterpret_cast<v4i *>(out + z4) = v4i{0, 0, 0, 0};
+                        if constexpr (REQ) *reinterpret_cast<uint32_t *>(out_q + z4) = 0u;
+                    }
                 }
             if (oy + 1 < oy1) {
                 if constexpr (S == 1) {
@@ -330,19 +337,19 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restr
 }
 
 template <bool REQ>
-int depthwise_launch(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e, int N, int H, int W, int C, int stride,
+int depthwise_launch(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e, int N, int H, int W, int C, int Cv, int stride,
                      int relu, int q_lo, int q_hi, int8_t *out_q, int32_t *out_acc, void *stream) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     HAWQ_REQUIRE(Ho > 0 && Wo > 0, "hawq_depthwise3x3: empty output");
     // rows per band: as tall as leaves ~4 waves per SIMD of the chip (2^18 threads), at most DW_MAX_BAND
-    const long long per_row = (long long)N * ((Wo + DW_PX - 1) / DW_PX) * (C / 4);
+    const long long per_row = (long long)N * ((Wo + DW_PX - 1) / DW_PX) * ((Cv + 3) / 4);
     long long band = per_row * Ho / (1 << 18);
     band = band < 1 ? 1 : (band > DW_MAX_BAND ? DW_MAX_BAND : band);
     if (band > Ho) band = Ho;
     const long long total = per_row * ((Ho + band - 1) / band);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     auto kern = stride == 1 ? depthwise3x3_kernel<REQ, 1> : depthwise3x3_kernel<REQ, 2>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, Ho, Wo, (int)band, out_acc, m, e, relu, q_lo, q_hi,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, Cv, Ho, Wo, (int)band, out_acc, m, e, relu, q_lo, q_hi,
                        out_q);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
@@ -353,16 +360,18 @@ extern "C" int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const in
                                  int32_t stride, int32_t *out_acc, void *stream) {
     HAWQ_REQUIRE(in && wgt9c && out_acc, "hawq_depthwise3x3: null pointer");
     HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
-    return depthwise_launch<false>(in, wgt9c, bias, nullptr, nullptr, N, H, W, C, stride, 0, 0, 0, nullptr, out_acc, stream);
+    return depthwise_launch<false>(in, wgt9c, bias, nullptr, nullptr, N, H, W, C, C, stride, 0, 0, 0, nullptr, out_acc, stream);
 }
 
 extern "C" int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e,
-                                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu, int32_t q_lo, int32_t q_hi,
-                                         int8_t *out_q, int32_t *out_acc, void *stream) {
+                                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t C_valid, int32_t stride, int32_t relu, int32_t q_lo,
+                                         int32_t q_hi, int8_t *out_q, int32_t *out_acc, void *stream) {
     HAWQ_REQUIRE(in && wgt9c && m && e && out_q, "hawq_depthwise3x3_requant: null pointer");
+    HAWQ_REQUIRE(C_valid >= 0 && C_valid <= C, "hawq_depthwise3x3_requant: C_valid=%d outside [0, C=%d]", C_valid, C);
+    HAWQ_REQUIRE(C_valid == 0 || C_valid == C || (q_lo <= 0 && q_hi >= 0), "hawq_depthwise3x3_requant: padding channels are written as 0, which the clamp must contain");
     HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3_requant: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
     HAWQ_REQUIRE(q_lo >= -128 && q_hi <= 127 && q_lo <= q_hi, "hawq_depthwise3x3_requant: the clamp must fit int8");
-    return depthwise_launch<true>(in, wgt9c, bias, m, e, N, H, W, C, stride, relu, q_lo, q_hi, out_q, out_acc, stream);
+    return depthwise_launch<true>(in, wgt9c, bias, m, e, N, H, W, C, C_valid > 0 ? C_valid : C, stride, relu, q_lo, q_hi, out_q, out_acc, stream);
 }
 
 

@@ -499,6 +499,16 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
                     for (int j = 0; j < 4; ++j)
                         if (ch + 4 * g + j < p.n_valid)
                             p.out_f32[(size_t)pix * p.ldo + ch + 4 * g + j] = (float)v[j] * p.fscale[ch + 4 * g + j];
+                } else if (p.n_valid > 0 && ch + 4 * g >= p.n_valid) {
+                    // padding channels (caller's promise: zero weights / bias / tables, zero identity): zeros without the arithmetic.
+                    // Narrow layers padded to the 64-channel tile (MobileNetV2's 16 / 24 / 32-channel projections) spend most of
+                    // this exact epilogue's 64-bit requants on them otherwise.
+                    if (EPI == HAWQ_EPI_RESIDUAL && p.res_out) {
+                        if (p.res_out_bits == 16) reinterpret_cast<v2i *>((uint16_t *)p.res_out + elem)[g] = v2i{0, 0};
+                        else reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[g] = v4i{0, 0, 0, 0};
+                    }
+                    if ((EPI == HAWQ_EPI_REQUANT || p.out_q) && p.out_bits == 8) reinterpret_cast<uint32_t *>((char *)p.out_q + elem)[g] = 0u;
+                    if ((EPI == HAWQ_EPI_REQUANT || p.out_q) && p.out_bits == 4 && !(g & 1)) reinterpret_cast<uint32_t *>((uint8_t *)p.out_q + (elem >> 1) + (g >> 1) * 4)[0] = 0u;
                 } else {
                     const v4i m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
                     const int mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};

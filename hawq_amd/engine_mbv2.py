@@ -299,6 +299,7 @@ class MobileNetV2Engine:
             if res_in is not None:
                 a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = res_in.data_ptr(), 32, m_id, e_id
             a.res_no_relu, a.res_clamp16 = int(not relu), int(clamp16)
+            a.n_valid = L.cout   # the exact epilogue skips the padding channels
             q = None
             if nxt_q is not None:
                 q = alloc(n * ho * wo * L.cout_p, torch.int8)
@@ -332,6 +333,8 @@ class MobileNetV2Engine:
                     if ent.get('fast'):
                         a.fast_tables, a.ctab = ent['fast'], ent['ctab'].data_ptr()
                         self.n_fast += 1
+                    else:
+                        a.n_valid = L.cout
                     if self.keep_acc:
                         self._tap(ops, keep, lname, a, N, ho, wo, L.cout, L.cout_p)
                     keep.append(a)
@@ -341,7 +344,7 @@ class MobileNetV2Engine:
                     if acc is not None:
                         self.taps[lname] = (acc, (N, ho, wo, L.cout_p), L.cout)
                     ops.append(partial(_lib.call, "hawq_depthwise3x3_requant", x.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), ent['m'].data_ptr(),
-                                       ent['e'].data_ptr(), N, h, w, L.cout_p, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
+                                       ent['e'].data_ptr(), N, h, w, L.cout_p, L.cout, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
                                        None if acc is None else acc.data_ptr(), sp))
                     keep.append(acc)
                 self.plan_bytes += N * (h * w * L.cin + ho * wo * L.cout) + L.weight_bytes

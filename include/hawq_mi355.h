@@ -93,7 +93,8 @@ typedef struct hawq_conv_args {
     int32_t *out_acc;     /* RAW: [M][Cout] int32                                              */
     float *out_f32;       /* DEQUANT: [M][ldo] fp32, only channels < n_valid are written       */
     const float *fscale;  /* DEQUANT: [Cout]                                                   */
-    int32_t ldo, n_valid;
+    int32_t ldo, n_valid; /* n_valid > 0 on the general REQUANT / RESIDUAL path (fast_tables == 0): channels >= n_valid are
+                             padding (zero weights, bias, tables and identity) and are written as zeros without arithmetic */
     int32_t *flags;       /* device int32: bit0 = uint16 residual overflow                     */
     int32_t tile;         /* 0 = heuristic; else tile config id (see hawq_conv2d_num_tiles)    */
     const int32_t *ctab;    /* fast path only: [Cout][4] = {m, (e-32)|k<<8, lo32(C), hi32(C)}, C = (bias<<k)*m + 2^(e-1) */
@@ -257,10 +258,11 @@ int hawq_depthwise3x3(const int8_t *in, const int8_t *wgt9c, const int32_t *bias
 /* The same with the conv's activation + QuantAct fused (conv2 -> ReLU6 -> quant_act2 of a MobileNetV2 unit, q_mobilenetv2.py:70-72;
  * ReLU6 == ReLU + the QuantAct's own clamp: its calibrated range never exceeds 6): out_q[N][Ho][Wo][C] int8 =
  * clamp(dyadic_rne(relu ? max(acc + bias, 0) : acc + bias, m[c], e[c]), q_lo, q_hi) with exact (tie-aware) rounding;
- * out_acc (optional) additionally receives the int32 accumulators. */
+ * out_acc (optional) additionally receives the int32 accumulators.  0 < C_valid < C: channels >= C_valid are padding up to the
+ * conv kernels' 64-channel tiles (zero weights / bias / m) - they are written as zeros and cost no loads or MACs (0 = all real). */
 int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e,
-                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t relu, int32_t q_lo, int32_t q_hi,
-                              int8_t *out_q, int32_t *out_acc, void *stream);
+                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t C_valid, int32_t stride, int32_t relu, int32_t q_lo,
+                              int32_t q_hi, int8_t *out_q, int32_t *out_acc, void *stream);
 
 /* Input QuantAct + im2col for a 3x3 / stride 2 / pad 1 first conv on 3 channels (MobileNetV2's init block, q_mobilenetv2.py:182-186
  * after quant_modules.py:271-274): x fp32 [N][3][H][W] -> out int8 [N][Ho][Wo][64], row = the 27 values

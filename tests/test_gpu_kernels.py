@@ -731,6 +731,8 @@ def test_depthwise3x3_requant_matches_accumulators_plus_host_dyadic(lib, orc, sh
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     ratio = torch.from_numpy(rng.uniform(2e-4, 3e-3, c).astype(f32))
     m, e = requant_table(ratio, torch.ones(c), torch.ones(1), lift=False)
+    if c >= 8:
+        m[-4:] = 0   # a padding channel group (multiplier 0): the kernel skips its loads and MACs, the result is still rne(acc * 0) = 0
     xd, w9, bd, md, ed = dev(x), dev(np.ascontiguousarray(wt.reshape(c, 9).T)), dev(b), dev(m), dev(e)
     acc = torch.zeros(n * ho * wo * c, dtype=torch.int32, device='cuda')
     lib.call("hawq_depthwise3x3", xd.data_ptr(), w9.data_ptr(), bd.data_ptr(), n, h, w, c, stride, acc.data_ptr(), stream())
@@ -740,16 +742,30 @@ def test_depthwise3x3_requant_matches_accumulators_plus_host_dyadic(lib, orc, sh
     for keep_acc in (True, False):
         q = torch.full((n * ho * wo * c,), 77, dtype=torch.int8, device='cuda')
         acc2 = torch.zeros_like(acc)
-        lib.call("hawq_depthwise3x3_requant", xd.data_ptr(), w9.data_ptr(), bd.data_ptr(), md.data_ptr(), ed.data_ptr(), n, h, w, c, stride,
+        lib.call("hawq_depthwise3x3_requant", xd.data_ptr(), w9.data_ptr(), bd.data_ptr(), md.data_ptr(), ed.data_ptr(), n, h, w, c, 0, stride,
                  relu, lo, hi, q.data_ptr(), acc2.data_ptr() if keep_acc else None, stream())
         assert np.array_equal(q.cpu().numpy().reshape(n, ho, wo, c).astype(np.int64), ref), (shape, keep_acc)
         assert not keep_acc or torch.equal(acc2, acc)
     assert ref.min() < 0 or relu
-    assert lib.load().hawq_depthwise3x3_requant(xd.data_ptr(), w9.data_ptr(), None, md.data_ptr(), ed.data_ptr(), n, h, w, c, stride, 0, -129, 127,
+    if c >= 8:   # padding channels declared (C_valid): same tensor with zeros there - their weights, bias and multipliers are zero by contract
+        wz, bz = wt.copy(), b.copy()
+        wz[c - 4:], bz[c - 4:] = 0, 0
+        q2 = torch.full_like(q, 55)
+        acc3 = torch.full_like(acc, 55)
+        wzd, bzd = dev(np.ascontiguousarray(wz.reshape(c, 9).T)), dev(bz)
+        lib.call("hawq_depthwise3x3_requant", xd.data_ptr(), wzd.data_ptr(), bzd.data_ptr(), md.data_ptr(),
+                 ed.data_ptr(), n, h, w, c, c - 4, stride, relu, lo, hi, q2.data_ptr(), acc3.data_ptr(), stream())
+        assert np.array_equal(q2.cpu().numpy().reshape(n, ho, wo, c).astype(np.int64), ref)
+        az = a.copy()
+        az[..., c - 4:] = 0
+        assert np.array_equal(acc3.cpu().numpy().reshape(n, ho, wo, c), az)
+    assert lib.load().hawq_depthwise3x3_requant(xd.data_ptr(), w9.data_ptr(), None, md.data_ptr(), ed.data_ptr(), n, h, w, c, 0, stride, 0, -129, 127,
+                                                q.data_ptr(), None, None) != 0
+    assert lib.load().hawq_depthwise3x3_requant(xd.data_ptr(), w9.data_ptr(), None, md.data_ptr(), ed.data_ptr(), n, h, w, c, c + 4, stride, 0, -128, 127,
                                                 q.data_ptr(), None, None) != 0
 
 
-@pytest.mark.parametrize("mode", ["linear", "linear_add", "relu_clamp_noid"])
+@pytest.mark.parametrize("mode", ["linear", "linear_add", "relu_clamp_noid", "linear_add_pad"])
 def test_residual_epilogue_without_relu_and_with_the_16_bit_clamp(lib, orc, mode):
     """The general RESIDUAL epilogue's MobileNetV2 switches (hawq_conv_args.res_no_relu / res_clamp16 / res_in == NULL):
     a linear bottleneck ends without an activation, so the 32-bit carrier holds signed values - requant(acc) [+ identity],
@@ -759,13 +775,19 @@ def test_residual_epilogue_without_relu_and_with_the_16_bit_clamp(lib, orc, mode
     rng = np.random.default_rng(len(mode))
     n, h, w, cin, cout = 2, 9, 7, 64, 128
     x, wt, b = make_conv(rng, n, h, w, cin, cout, 1, 8, 8)
+    pad_from = 72 if mode == "linear_add_pad" else cout   # n_valid: channels from here on are padding and skip the arithmetic
+    wt[pad_from:], b[pad_from:] = 0, 0
     a, keep = conv_args(lib, x, wt, b, 1, 0, 8, 8)
+    a.n_valid = pad_from if mode == "linear_add_pad" else 0
+    mode = "linear_add" if mode == "linear_add_pad" else mode
     acc = orc.conv2d(x, wt, b, 1, 0)
     ratio = torch.from_numpy(rng.uniform(0.5, 3.0, cout).astype(f32))   # wide enough to leave the 16-bit range
     m2, e2 = requant_table(ratio, torch.ones(cout), torch.ones(1), lift=False)
+    m2[pad_from:] = 0
     v = odyadic(orc, acc, m2, e2)
     if mode == "linear_add":
         res = rng.integers(-30000, 30000, (n, cout, h, w)).astype(np.int64)
+        res[:, pad_from:] = 0
         m1, e1 = requant_table(torch.tensor([0.81]), torch.ones(1), torch.ones(1), lift=False)
         keep['res'] = dev(nhwc(res).astype(np.int32))
         a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = keep['res'].data_ptr(), 32, int(m1[0]), int(e1[0])
@@ -783,8 +805,8 @@ def test_residual_epilogue_without_relu_and_with_the_16_bit_clamp(lib, orc, mode
     ref_q = odyadic(orc, v, mq, eq, (lo, hi))
     md, ed = dev(m2), dev(e2)
     flags = torch.zeros(1, dtype=torch.int32, device='cuda')
-    out_res = torch.zeros(v.size, dtype=torch.int32, device='cuda')
-    out_q = torch.zeros(v.size, dtype=torch.int8, device='cuda')
+    out_res = torch.full((v.size,), 7, dtype=torch.int32, device='cuda')
+    out_q = torch.full((v.size,), 7, dtype=torch.int8, device='cuda')
     a.epilogue, a.m, a.e, a.flags = lib.EPI_RESIDUAL, md.data_ptr(), ed.data_ptr(), flags.data_ptr()
     a.res_out, a.res_out_bits = out_res.data_ptr(), 32
     a.out_q, a.out_bits, a.q_lo, a.q_hi, a.mq, a.eq = out_q.data_ptr(), 8, lo, hi, int(mq[0]), int(eq[0])
