@@ -410,13 +410,16 @@ class IntegerEngine:
             # plans for this chain count replays faster
             if N >= 8 and plans.get(self.chains) is not None:
                 cands = [plans[self.chains], self._plan_snapshot()]
-                for _ in range(max(0, int(os.environ.get("HAWQ_TUNE_TRIALS", "3")) - 2)):
+                for _ in range(max(0, int(os.environ.get("HAWQ_TUNE_TRIALS", "4")) - 2)):
                     self._build_chains(N, H, W, x_view, logits_view)
                     cands.append(self._plan_snapshot())
-                times = []
-                for pl in cands:   # all on the final buffers, one after the other
-                    self._plan_apply(pl)
-                    times.append(self._time_graph(16))
+                # all on the final buffers, in two interleaved rounds (a plan's replay time drifts by ~1 % with the clocks: the
+                # second round keeps one lucky measurement from deciding), the faster of a plan's two times counts
+                times = [float("inf")] * len(cands)
+                for _ in range(2):
+                    for i, pl in enumerate(cands):
+                        self._plan_apply(pl)
+                        times[i] = min(times[i], self._time_graph(24))
                 self._plan_apply(cands[times.index(min(times))])
                 self.plan_trials_ms = tuple(round(t, 4) for t in times)
             return
@@ -482,8 +485,12 @@ class IntegerEngine:
             self.x_in = torch.empty(N, 3, H, W, dtype=torch.float32, device=dev)
             self.logits = torch.empty(N, P['fc']['nout'], dtype=torch.float32, device=dev)
             self.subs, b0 = [], 0
+            # HAWQ_SPLIT="72,56": measurement switch - uneven sub-batches (profiles/r03_uneven_split.md)
+            split = [int(v) for v in os.environ.get("HAWQ_SPLIT", "").split(",") if v]
+            if len(split) != self.chains or sum(split) != N or min(split) < 1:
+                split = [N // self.chains + (1 if i < N % self.chains else 0) for i in range(self.chains)]
             for i in range(self.chains):
-                b1 = b0 + N // self.chains + (1 if i < N % self.chains else 0)
+                b1 = b0 + split[i]
                 sub = IntegerEngine(None, _parent=self)
                 sub._build(b1 - b0, H, W, self.x_in[b0:b1], self.logits[b0:b1])
                 self.subs.append(sub)
