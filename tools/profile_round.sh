@@ -55,3 +55,36 @@ json.dump(out, open("$O/${tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 cat $O/${tag}_pmc_totals.txt
+# the same two counter passes for the lower-precision schedules (their own tuned plan, replayed): does the traffic shrink with the bit width?
+for scheme in ${TRAFFIC_SCHEMES:-uniform4}; do
+  unset HAWQ_TILES HAWQ_CHAINS HAWQ_ER_TILES HAWQ_ER_SPLIT_TILES
+  cd $R; python bench.py --scheme $scheme --no-cpu-baseline --no-extra > $O/${tag}_bench_${scheme}.json 2>/dev/null; cd /tmp
+  cfg2() { python -c "import json; print(json.loads(open('$O/${tag}_bench_${scheme}.json').readline())['config']['$1'])"; }
+  export HAWQ_TILES=$(cfg2 autotuned_tiles) HAWQ_CHAINS=$(cfg2 concurrent_sub_batches) HAWQ_ER_TILES=$(cfg2 fused_variants) HAWQ_ER_SPLIT_TILES=$(cfg2 fused_split_tiles)
+  rm -f $O/${tag}_pmc_totals_${scheme}.txt
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    for steps in 2 12; do
+      rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm -o r -- python $R/bench.py --scheme $scheme --no-cpu-baseline --no-extra --steps $steps --warmup 1 > /dev/null 2>&1
+      echo "$ctr steps=$steps $(python $R/tools/pmc_total.py $(find /tmp/pm -name '*.db' | head -1))" >> $O/${tag}_pmc_totals_${scheme}.txt
+    done
+  done
+  python - <<PY
+import json, re
+tot = {}
+for line in open("$O/${tag}_pmc_totals_${scheme}.txt"):
+    m = re.match(r"(\w+) steps=(\d+) \1 ([\d.e+]+) (\d+)", line)
+    if m:
+        tot[(m[1], int(m[2]))] = float(m[3])
+fetch_kb = (tot[("FETCH_SIZE", 12)] - tot[("FETCH_SIZE", 2)]) / 10
+write_kb = (tot[("WRITE_SIZE", 12)] - tot[("WRITE_SIZE", 2)]) / 10
+b = json.loads(open("$O/${tag}_bench_${scheme}.json").readline())
+out = json.load(open("$O/${tag}_traffic.json"))
+out[b["config"]["workload"]] = {
+    "bytes_per_launch": round((2 * fetch_kb + write_kb) * 1024.0), "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
+    "git_head": "${GRAFT_HEAD:-unknown}", "tag": "$tag", "fused_pairs": b["config"].get("fused_pairs", []),
+    "plan": {"tiles": b["config"]["autotuned_tiles"], "fused_variants": b["config"]["fused_variants"], "chains": b["config"]["concurrent_sub_batches"]},
+    "images_per_s_of_the_plan_run": b["value"], "method": "as for the headline workload (see its entry)"}
+json.dump(out, open("$O/${tag}_traffic.json", "w"), indent=1)
+print("$scheme", out[b["config"]["workload"]]["bytes_per_launch"])
+PY
+done
