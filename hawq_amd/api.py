@@ -45,6 +45,10 @@ def calibrate(model, images: torch.Tensor):
 
 # ------------------------------------------------------------------ quantized checkpoints (quant_train.py:665-670)
 _QCKPT_GROUPS = ("convbn_scaling_factor", "fc_scaling_factor", "weight_integer", "bias_integer", "act_scaling_factor")
+# The reference's five groups omit QuantConv2d's own scale buffer (MobileNetV2's classifier, quant_modules.py:627-634): a file it
+# writes cannot restore that network by itself.  Ours adds the group when the model has such buffers (the reference's loader
+# ignores unknown groups); loading a file without it into such a model is refused instead of running on a placeholder scale.
+_QCKPT_EXTRA = ("conv_scaling_factor",)
 
 
 def save_quantized_checkpoint(model, path):
@@ -52,7 +56,12 @@ def save_quantized_checkpoint(model, path):
     (quant_train.py:665-670): five dicts of the frozen model's integer weights / biases and scales, keyed by
     the ``state_dict`` names.  Call after a frozen forward (the buffers are filled by it)."""
     sd = model.state_dict()
-    torch.save({g: {k: v.detach().cpu() for k, v in sd.items() if g in k} for g in _QCKPT_GROUPS}, path)
+    out = {g: {k: v.detach().cpu() for k, v in sd.items() if g in k} for g in _QCKPT_GROUPS}
+    for g in _QCKPT_EXTRA:
+        extra = {k: v.detach().cpu() for k, v in sd.items() if k.rpartition(".")[2] == g}
+        if extra:
+            out[g] = extra
+    torch.save(out, path)
 
 
 def load_quantized_checkpoint(model, ckpt, strict: bool = True):
@@ -67,14 +76,14 @@ def load_quantized_checkpoint(model, ckpt, strict: bool = True):
     if missing:
         raise KeyError(f"not a HAWQ quantized checkpoint: missing {missing}")
     flat = {}
-    for g in _QCKPT_GROUPS:
+    for g in _QCKPT_GROUPS + tuple(g for g in _QCKPT_EXTRA if g in ckpt):
         # validate() saves the state_dict of the DataParallel-wrapped model (quant_train.py:358, 665-670): real HAWQ
         # files carry 'module.'-prefixed keys; the TVM loader strips them the same way (hawq_utils_resnet50.py:479-485)
         flat.update({(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt[g].items()})
     own = dict(model.named_buffers())
     own.update(dict(model.named_parameters()))
     unexpected = [k for k in flat if k not in own]
-    wanted = [k for k in own if any(g in k for g in _QCKPT_GROUPS)]
+    wanted = [k for k in own if any(g in k for g in _QCKPT_GROUPS) or k.rpartition(".")[2] in _QCKPT_EXTRA]
     absent = [k for k in wanted if k not in flat]
     if strict and (unexpected or absent):
         raise KeyError(f"quantized checkpoint does not match the model: unexpected {unexpected[:3]}..., missing {absent[:3]}...")

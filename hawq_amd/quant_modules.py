@@ -128,7 +128,8 @@ class QuantAct(Module):
 
         if self.full_precision_flag:
             return x
-        self.compute_scale()
+        if not (getattr(self, "use_integer_buffers", False) and not self.running_stat):
+            self.compute_scale()   # else: act_scaling_factor as loaded from a quantized checkpoint (the file carries no x_min / x_max)
         if (pre_act_scaling_factor is None) or (self.fixed_point_quantization is True):
             quant_act_int = self.act_function(x, self.activation_bit, self.act_scaling_factor)
         elif type(pre_act_scaling_factor) is list:
@@ -545,7 +546,7 @@ _QUANT_TYPES = (QuantAct, QuantConv2d, QuantLinear, QuantBnConv2d)
 
 
 def trust_integer_buffers(model, flag: bool):
-    """Mark every weight-carrying quantized module of `model` as running on its LOADED integer buffers / scales
+    """Mark every quantized module of `model` as running on its LOADED integer buffers / scales
     (quantized_checkpoint.pth.tar, quant_train.py:665-670) - or, ``flag`` False, as deriving them from its float parameters
     again.  The module path (forward_modules, Q_MobileNetV2) reads this per module; the fused ResNet engine reads
     ``model.engine_defaults['from_buffers']``: hawq_amd.api keeps both in step."""
@@ -553,6 +554,8 @@ def trust_integer_buffers(model, flag: bool):
         if isinstance(m, (QuantBnConv2d, QuantConv2d, QuantLinear)):
             m.use_integer_buffers = bool(flag)
             m._prep_key = None
+        elif isinstance(m, QuantAct):   # a frozen QuantAct then keeps the loaded act_scaling_factor instead of deriving it from x_min / x_max
+            m.use_integer_buffers = bool(flag)
 
 
 def freeze_model(model):

@@ -164,6 +164,8 @@ def test_network_restored_from_checkpoint_alone(tmp_path, arch, scheme):
     yb = b(x)
     assert b._engine is not None and b._engine.from_buffers
     assert torch.equal(ya, yb)
+    with torch.no_grad():   # the module-by-module path runs on the loaded integers and activation scales too
+        assert torch.equal(b.forward_modules(x), a.forward_modules(x))
     # ... and from the bit-packed archive of the same checkpoint (hawq_amd.bitpack)
     from hawq_amd import bitpack
     packed = str(tmp_path / "packed.pth.tar")
@@ -171,6 +173,35 @@ def test_network_restored_from_checkpoint_alone(tmp_path, arch, scheme):
     c = build_quantized_resnet(arch, scheme, seed=11).cuda()
     bitpack.load_packed_checkpoint(c, packed)
     assert torch.equal(c(x), ya)
+
+
+@pytest.mark.gpu
+def test_mobilenetv2_restored_from_checkpoint_alone(tmp_path):
+    """Q_MobileNetV2 save -> load into a network with unrelated float weights: the fused plan AND the module path must run on the
+    loaded integers (a model without the ResNet engine silently re-quantised its synthetic floats).  The reference's five
+    checkpoint groups omit QuantConv2d's scale buffer (the classifier): our file carries it in a sixth group, and a file without it
+    is refused instead of running on a placeholder scale."""
+    from hawq_amd.api import build_quantized_model, calibrate, load_quantized_checkpoint, save_quantized_checkpoint
+    from hawq_amd.skeleton import synthetic_images
+    x = synthetic_images(4, seed=3).cuda()
+    a = build_quantized_model("mobilenetv2_w1", "uniform8", seed=0).cuda()
+    calibrate(a, synthetic_images(8, seed=0).cuda())
+    ya = a(x).clone()
+    with torch.no_grad():
+        ya_mod = a.forward_modules(x).clone()
+    path = str(tmp_path / "quantized_checkpoint.pth.tar")
+    save_quantized_checkpoint(a, path)
+    ck = torch.load(path, map_location="cpu")
+    assert list(ck["conv_scaling_factor"]) == ["output.conv_scaling_factor"]
+    b = build_quantized_model("mobilenetv2_w1", "uniform8", seed=9).cuda()   # unrelated float weights, never calibrated
+    load_quantized_checkpoint(b, path)
+    assert torch.equal(b(x), ya) and b._engine is not None and b._engine.from_buffers
+    with torch.no_grad():
+        assert torch.equal(b.forward_modules(x), ya_mod)
+    del ck["conv_scaling_factor"]      # what the reference's validate() would have written
+    c = build_quantized_model("mobilenetv2_w1", "uniform8", seed=9).cuda()
+    with pytest.raises(KeyError):
+        load_quantized_checkpoint(c, ck)
 
 
 def test_bitpack_round_trip_and_size(tmp_path):
