@@ -31,6 +31,7 @@ All convs run the exact general kernels (``fast_tables = 0``: any e, ties handle
 from __future__ import annotations
 
 import ctypes as C
+import os
 from functools import partial
 
 import numpy as np
@@ -265,6 +266,7 @@ class MobileNetV2Engine:
         if self._graph is not None:
             _lib.call("hawq_graph_destroy", self._graph)
         ops, keep, self.taps, self._graph = [], [], {}, None
+        self._convs, self._tuned = [], False   # hawq_conv2d argument structs of the plan (tile autotuning)
         self.n_fast = 0
         self.plan_bytes = N * 3 * H * W * 4   # bytes the plan has to move at the networks' true widths (no padding channels)
         alloc = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
@@ -307,6 +309,7 @@ class MobileNetV2Engine:
             if self.keep_acc:
                 self._tap(ops, keep, name, a, n, ho, wo, L.cout, L.cout_p)
             keep.extend([a, out16, q])
+            self._convs.append((name, a))
             ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
             if out16 is not None:
                 self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_p), L.cout)
@@ -338,6 +341,7 @@ class MobileNetV2Engine:
                     if self.keep_acc:
                         self._tap(ops, keep, lname, a, N, ho, wo, L.cout, L.cout_p)
                     keep.append(a)
+                    self._convs.append((lname, a))
                     ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
                 else:
                     acc = alloc(N * ho * wo * L.cout_p, torch.int32) if self.keep_acc else None
@@ -376,12 +380,56 @@ class MobileNetV2Engine:
         a.out_f32, a.fscale, a.ldo, a.n_valid = self.logits.data_ptr(), fc['fscale'].data_ptr(), fc['nout'], fc['nout']
         if self.keep_acc:
             self._tap(ops, keep, "output", a, N, 1, 1, fc['nout'], fc['nout_p'])
+        self._convs.append(("output", a))
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
         keep += [qf, pooled, a]
         self._ops, self._keep, self._batch = ops, keep, (N, H, W)
 
+    def _autotune(self, reps: int = 3):
+        """Time every hawq_conv2d launch of the plan with each tile configuration the library accepts for it (HIP events on the
+        engine stream, the real buffers - every tile gives the same integers) and keep the fastest; two rounds, per-tile minimum.
+        HAWQ_MBV2_TILES replays a dotted list (as `tile_choice` prints it), HAWQ_MBV2_TILES=0 keeps the library's heuristic."""
+        self._tuned = True
+        fixed = os.environ.get("HAWQ_MBV2_TILES")
+        if fixed is not None:
+            ids = [int(v) for v in fixed.split(".")]
+            for (_, a), t in zip(self._convs, ids if len(ids) == len(self._convs) else [0] * len(self._convs)):
+                a.tile = t
+            return
+        lib, sp = _lib.load(), self.stream.cuda_stream
+        n_tiles = lib.hawq_conv2d_num_tiles() - lib.hawq_conv2d_num_band_tiles()   # the 3x3 band tiles are not for 1x1 layers
+        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+        _lib.call("hawq_event_create", C.byref(e0))
+        _lib.call("hawq_event_create", C.byref(e1))
+        for _, a in self._convs:
+            times = {}
+            for rnd in range(2):
+                for tile in range(1, n_tiles + 1):
+                    if rnd and tile not in times:
+                        continue
+                    a.tile = tile
+                    if lib.hawq_conv2d(C.byref(a), sp) != 0:   # this tile does not take the launch
+                        continue
+                    _lib.call("hawq_event_record", e0, sp)
+                    for _ in range(reps):
+                        _lib.call("hawq_conv2d", C.byref(a), sp)
+                    _lib.call("hawq_event_record", e1, sp)
+                    _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
+                    times[tile] = min(times.get(tile, ms.value), ms.value)
+            a.tile = min(times, key=times.get) if times else 0
+        _lib.call("hawq_event_destroy", e0)
+        _lib.call("hawq_event_destroy", e1)
+
+    @property
+    def tile_choice(self):
+        return ".".join(str(a.tile) for _, a in self._convs)
+
     # ------------------------------------------------------------------ execution
     def run_resident(self):
+        if not self._tuned and not self.keep_acc:
+            for op in self._ops:   # every buffer holds valid data before launches are timed on it
+                op()
+            self._autotune()
         if self.use_graph:
             if self._graph is None:
                 for op in self._ops:   # warm-up outside capture
