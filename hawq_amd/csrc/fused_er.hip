@@ -35,6 +35,7 @@ struct ERP {
     int m_id_s, e_id_s, mq, eq, q_hi;  // scalar tables: identity pass-through, QuantAct of unit i+1 (q >= 0: post-ReLU)
     int y_lo, y_hi;                    // clamp of the reduce conv's QuantAct (ReLU folded into y_lo)
     int y_planar;
+    int y_nib;                         // the reduce conv's output is stored hawq4 (4-bit values, two channels per byte) for a nibble 3x3 conv
     int32_t *flags;
     int dbg;             // HAWQ_DBG ablations (timing experiments only): 256 = no residual stores, 512 = no residual loads
     long long *dbgbuf;   // HAWQ_DBG=128: per-phase cycle sums of wave 0 of workgroup 8 (timing experiments only)
@@ -363,6 +364,38 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_kernel(const ERP
     {
         constexpr int CPR = F::C / 16;   // 16-byte chunks per output row
         char *yt = ring;
+        if (p.y_nib) {
+            // hawq4 output (the next 3x3 conv runs its nibble pipeline): 16 channels of a lane = 8 bytes, byte k of an 8-channel
+            // group = c_k | c_{k+4} << 4 (include/hawq_mi355.h); rows are C / 2 bytes, 16-byte chunks hold 32 channels
+            constexpr int CPN = F::C / 32;
+#pragma unroll
+            for (int c = 0; c < F::CT2; ++c) {
+                const int ch0 = wave_c * (F::CT2 * 32) + c * 32 + h * 16;
+                int qv[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    qv[k] = med3i(dyadic_mode<MODE_C>(acc2[c][k], ctab_entry<K0>((const char *)p.ctab1, ch0 + k)), p.y_lo, p.y_hi);
+                const v2i ww = {(int)pack8_u4(&qv[0]), (int)pack8_u4(&qv[8])};
+                *reinterpret_cast<v2i *>(yt + (arow * CPN + ((ch0 >> 5) ^ (arow & (CPN - 1)))) * 16 + ((ch0 >> 4) & 1) * 8) = ww;
+            }
+            __syncthreads();
+            if (p.y_planar) {   // planes [C / 32][M][16 B]
+                for (int idx = t; idx < F::BM * CPN; idx += F::NTC) {
+                    const int ch = idx / F::BM, row = idx % F::BM;
+                    if (m0 + row < p.M)
+                        *reinterpret_cast<v4i *>((char *)p.y + ((size_t)ch * p.M + (m0 + row)) * 16) =
+                            *reinterpret_cast<const v4i *>(yt + (row * CPN + (ch ^ (row & (CPN - 1)))) * 16);
+                }
+            } else {
+                for (int idx = t; idx < F::BM * CPN; idx += F::NTC) {
+                    const int row = idx / CPN, jj = idx % CPN;
+                    if (m0 + row < p.M)
+                        *reinterpret_cast<v4i *>((char *)p.y + (size_t)(m0 + row) * (F::C / 2) + ((jj ^ (row & (CPN - 1))) << 4)) =
+                            *reinterpret_cast<const v4i *>(yt + idx * 16);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < F::CT2; ++c) {
             const int ch0 = wave_c * (F::CT2 * 32) + c * 32 + h * 16;
@@ -437,7 +470,8 @@ int er_variant(const hawq_expand_reduce_args *a) {
     if (e.epilogue != HAWQ_EPI_RESIDUAL || r.epilogue != HAWQ_EPI_REQUANT) return -1;
     if (!dual && (!e.res_in || e.res_in_bits != 16)) return -1;
     if (!e.res_out || e.res_out_bits != 16 || !e.flags || !e.ctab || !r.ctab || !r.out_q) return -1;
-    if (r.out_bits != 8 || e.out_bits != 8) return -1;
+    if ((r.out_bits != 8 && r.out_bits != 4) || e.out_bits != 8) return -1;
+    if (r.out_bits == 4 && (r.q_lo < 0 || r.q_hi > 15)) return -1;   // hawq4 stores unsigned nibbles
     if (r.Cin != e.Cout || r.Cout != e.Cin || r.N != e.N || r.H != e.H || r.W != e.W || e.Cout % 64) return -1;
     int nth = 0, first = -1;
     for (int i = 0; i < NUM_ER; ++i)
@@ -494,6 +528,7 @@ extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *s
     p.m_id_s = e.in2 ? 0 : e.m_id_scalar, p.e_id_s = e.in2 ? 33 : e.e_id_scalar, p.mq = e.mq, p.eq = e.eq, p.q_hi = e.q_hi;
     p.y_lo = r.relu && r.q_lo < 0 ? 0 : r.q_lo, p.y_hi = r.q_hi;
     p.y_planar = r.out_planar;
+    p.y_nib = r.out_bits == 4;
     p.flags = e.flags;
     static const int dbg_env = HAWQ_DBG_ENV();
     static long long *dbg_dev = nullptr;

@@ -40,7 +40,7 @@ struct WPP {
     uint8_t *q_out;      // !REDUCE: block input of the next unit [M][C3] int8, or null
     int M, C3;
     int m_id_s, e_id_s, mq, eq, q_hi;
-    int y_lo, y_hi, y_planar;
+    int y_lo, y_hi, y_planar, y_nib;   // y_nib: the reduce conv's output is stored hawq4 (two 4-bit channels per byte)
     int spb;             // slices per workgroup along gridDim.y (REDUCE: all of them)
     int32_t *flags;
     long long *dbgbuf;   // probe builds (HAWQ_ABLATE, HAWQ_DBG=128): per-phase cycle sums of wave 0 of workgroup 8
@@ -347,7 +347,14 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
                 w[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
             }
             const v4i ww = {w[0], w[1], w[2], w[3]};
-            if (valid) {
+            if (valid && p.y_nib) {
+                // hawq4: byte k of an 8-channel group = c_k | c_{k+4} << 4; the int8 dwords hold 4 channels each, values 0..15
+                const v2i nn = {w[0] | (w[1] << 4), w[2] | (w[3] << 4)};
+                if (p.y_planar)   // planes [C / 32][M][16 B]
+                    *reinterpret_cast<v2i *>((char *)p.y + ((size_t)(ch0 >> 5) * p.M + row) * 16 + ((ch0 >> 4) & 1) * 8) = nn;
+                else
+                    *reinterpret_cast<v2i *>((char *)p.y + row * (C / 2) + (ch0 >> 1)) = nn;
+            } else if (valid) {
                 if (p.y_planar)   // channel-group planes [C / 16][M][16 B] (hawq_conv_args.out_planar)
                     *reinterpret_cast<v4i *>((char *)p.y + ((size_t)(ch0 >> 4) * p.M + row) * 16) = ww;
                 else
@@ -391,7 +398,8 @@ int wp_variant(const hawq_expand_reduce_args *a, int nth) {
     const bool reduce = r.wgt != nullptr;
     if (reduce) {
         if (!(r.KH == 1 && r.KW == 1 && r.stride == 1 && r.pad == 0 && r.in_bits == 8 && r.w_bits == 8 && r.fast_tables != 0 && !r.in2)) return -1;
-        if (r.epilogue != HAWQ_EPI_REQUANT || !r.ctab || !r.out_q || r.out_bits != 8 || !e.res_out) return -1;
+        if (r.epilogue != HAWQ_EPI_REQUANT || !r.ctab || !r.out_q || (r.out_bits != 8 && r.out_bits != 4) || !e.res_out) return -1;
+        if (r.out_bits == 4 && (r.q_lo < 0 || r.q_hi > 15)) return -1;   // hawq4 stores unsigned nibbles
         if (r.Cin != e.Cout || r.Cout != e.Cin || r.N != e.N || r.H != e.H || r.W != e.W) return -1;
     }
     int n = 0;
@@ -429,6 +437,7 @@ int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     p.m_id_s = e.m_id_scalar, p.e_id_s = e.e_id_scalar, p.mq = e.mq, p.eq = e.eq, p.q_hi = e.q_hi;
     p.y_lo = wi.reduce ? (r.relu && r.q_lo < 0 ? 0 : r.q_lo) : 0, p.y_hi = wi.reduce ? r.q_hi : 0;
     p.y_planar = wi.reduce ? r.out_planar : 0;
+    p.y_nib = wi.reduce && r.out_bits == 4;
     p.spb = (e.Cout / 64) / wi.ysplit;
     p.flags = e.flags;
     p.dbgbuf = nullptr;

@@ -198,7 +198,13 @@ class IntegerEngine:
                          fast=tables_are_fast(mm, ee, sc.vbits))
         s_prev = s0
         units = []
-        for name, u in m.units():
+        unit_list = list(m.units())
+
+        def block_input_bits(unit):
+            return self._storage(self._store_bits(unit.quant_act), [unit.quant_convbn1] + ([unit.quant_identity_convbn] if unit.resize_identity else []))
+
+        for ui, (name, u) in enumerate(unit_list):
+            nxt_u = unit_list[ui + 1][1] if ui + 1 < len(unit_list) else None
             d = dict(name=name, resize=bool(u.resize_identity), nb=u.n_body)
             qa = u.quant_act
             s_a = self._scale(qa)
@@ -219,8 +225,17 @@ class IntegerEngine:
                     act = getattr(u, f"quant_act{i}")
                     s_n = self._scale(act)
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
-                    ent.update(m=_i32(mm, dev), e=_i32(ee, dev),
-                               out_bits=self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")]),
+                    store = self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")])
+                    if (store == 4 and u.n_body == 3 and i + 1 == u.n_body and int(name.split('.')[0][len('stage'):]) in self.fuse_stages
+                            and nxt_u is not None and not nxt_u.resize_identity and block_input_bits(nxt_u) == 8
+                            and os.environ.get("HAWQ_EXPAND_IN8", "1") != "0"):
+                        # Mixed schedules (8-bit block inputs, 4-bit tensors inside the units): the 4-bit input of an expand conv
+                        # whose successor's reduce conv runs the int8 pipeline anyway is stored as int8, so that the fused
+                        # expand -> reduce launch takes the pair (it packs the reduce conv's 4-bit output itself).  Measured
+                        # (tools/nibble_pairs_ab.sh): bops_0.5 +1.6 %; pure W4A4 - whose block inputs are nibbles too - LOSES
+                        # 1.3 % with its pairs fused on int8 operands and keeps its nibble launches.
+                        store = 8
+                    ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=store,
                                rng=_act_range(act.activation_bit, act.quant_mode),
                                fast=tables_fit_fast(mm, ee, c.vbits), tie=not tables_are_fast(mm, ee, c.vbits),
                                k0=_no_preshift(ee), ck0=_no_preshift(ee))
@@ -338,8 +353,9 @@ class IntegerEngine:
             return None
         ent = nxt['convs'][0]
         c = ent['conv']
-        if not ent.get('fast', False) or ent['out_bits'] != 8 or a.in_bits != 8 or a.w_bits != 8:
+        if not ent.get('fast', False) or ent['out_bits'] not in (4, 8) or a.in_bits != 8 or a.w_bits != 8:
             return None
+        ob = ent['out_bits']   # 4: the reduce conv's output feeds a nibble 3x3 conv - the fused kernels pack it (hawq4) themselves
         er = _lib.ExpandReduceArgs()
         C.memmove(C.byref(er.expand), C.byref(a), C.sizeof(a))
         er.expand.out_q, er.expand.out_bits = None, 8   # the block input of the next unit stays on chip (its storage width is moot)
@@ -354,14 +370,14 @@ class IntegerEngine:
         r.m, r.e, r.ctab = ent['m'].data_ptr(), ent['e'].data_ptr(), ent['ctab'].data_ptr()
         r.flags = self.flags.data_ptr()
         r.epilogue, r.relu = _lib.EPI_REQUANT, 1
-        r.out_bits, r.q_lo, r.q_hi = 8, ent['rng'][0], ent['rng'][1]
+        r.out_bits, r.q_lo, r.q_hi = ob, ent['rng'][0], ent['rng'][1]
         r.fast_tables = (5 if ent.get('tie', False) else 1) | (8 if ent.get('ck0', False) else 0)
         r.out_q = 1  # placeholder for the applicability query
         if _lib.load().hawq_conv_expand_reduce_variants(C.byref(er)) == 0:
             return None
-        out = self._alloc(N * ho * wo * c.cout, torch.uint8)
+        out = self._alloc(N * ho * wo * c.cout * ob // 8, torch.uint8)
         r.out_q = out.data_ptr()
-        planar = self.planar and self._band_takes(nxt['convs'][1], N, ho, wo, 8, False, nxt)
+        planar = self.planar and self._band_takes(nxt['convs'][1], N, ho, wo, ob, False, nxt)
         r.out_planar = int(planar)
         # the same two layers as separate launches (the block input q then goes through memory)
         q = self._alloc(N * ho * wo * c.cin * nxt['a_bits'] // 8, torch.uint8)
@@ -372,7 +388,7 @@ class IntegerEngine:
         r1.wgt, r1.w_bits = c.w.data_ptr(), c.w_bits
         pair = _FusedPair(er, a, r1, self.stream.cuda_stream)
         keep += [out, er, q, r1, pair]
-        return pair, out, 8, planar
+        return pair, out, ob, planar
 
     def _try_solo(self, a, u, keep):
         """Expand conv launch `a` (RESIDUAL epilogue, single branch, completely filled) as a candidate for the

@@ -111,6 +111,33 @@ def test_expand_reduce_matches_oracle(lib, orc, shape, tie):
     assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 14, 14, 128, 512), (3, 9, 7, 128, 512), (1, 14, 14, 256, 1024), (2, 28, 28, 128, 512)])
+def test_expand_reduce_nibble_output(lib, orc, shape):
+    """The reduce conv's output stored hawq4 (reduce.out_bits = 4: a 4-bit QuantAct in front of a nibble 3x3 conv - W4A4 and the
+    mixed schedules): every variant of both fused kernel families packs two channels per byte itself, NHWC rows and planes;
+    clamp(v, 0, 15) of the same accumulators the int8 case requantises."""
+    n, h, w, c, c3 = shape
+    a, keep, o, y = _case(lib, orc, n, h, w, c, c3, zlib.crc32(repr(shape).encode()) + 4)
+    y4 = np.minimum(y, 15)
+    assert (y4 == 15).any() and (y4 < 15).any()
+    a.reduce.out_bits, a.reduce.q_lo, a.reduce.q_hi = 4, 0, 15
+    nvar = lib.load().hawq_conv_expand_reduce_variants(C.byref(a))
+    assert nvar >= 1
+    for tile in range(0, nvar + 1):
+        for planar in (0, 1):
+            a.tile, a.reduce.out_planar = tile, planar
+            keep['res_out'].zero_(), keep['y'].fill_(0xAB)
+            lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+            got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+            assert np.array_equal(got, o), (tile, planar)
+            packed = keep['y'][:y.size // 2]
+            gy = from_planar(packed, (n, h, w, c), 4) if planar else unpack_q(packed, (n, h, w, c), 4)
+            assert np.array_equal(gy, y4), (tile, planar)
+            assert (keep['y'][y.size // 2:] == 0xAB).all()   # nothing written past the packed tensor
+    a.reduce.q_hi = 16   # does not fit a nibble
+    assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
+
+
 @pytest.mark.parametrize("shape", [(2, 14, 14, 64, 256), (3, 9, 7, 128, 512), (1, 14, 14, 256, 1024), (2, 7, 7, 512, 2048),
                                    (1, 3, 5, 128, 256), (128, 7, 7, 512, 2048), (16, 28, 28, 128, 512)])
 @pytest.mark.parametrize("tie", [False, True])
