@@ -147,7 +147,9 @@ int hawq_conv2d_band_tile(const hawq_conv_args *args);
  * on chip.  Needs: both convs 1x1 / stride 1, int8 operands, fast_tables != 0, uint16 residual in and out (single
  * branch) - or, for expand.Cin == 64, a second branch in2 / wgt2 / ctab_id that is a 1x1 / stride-1 conv over the same pixels with
  * Cin2 == 64 (the first unit of ResNet50's stage 1: its requantised accumulators replace the stored residual) -,
- * reduce.Cin == expand.Cout, reduce.Cout == expand.Cin in {64, 128, 256}, 8-bit outputs.
+ * reduce.Cin == expand.Cout, reduce.Cout == expand.Cin in {64, 128, 256}; reduce.out_bits 8, or 4 (round 3: the reduce conv's QuantAct
+ * is 4-bit and a nibble 3x3 conv follows - the launch packs hawq4 itself, NHWC rows of Cout / 2 bytes or planes [Cout / 32][M][16 B];
+ * needs 0 <= q_lo, q_hi <= 15).
  * tile: 0 = default kernel variant for the channel count, 1..hawq_conv_expand_reduce_variants() = a specific one (the variants of
  * fused_er.hip first, then the wave-private ones of fused_wp.hip: same results, different organisation of the launch).
  * reduce.wgt == NULL (round 3): the expand conv ALONE on the wave-private kernel - `expand` exactly as for hawq_conv2d with the
