@@ -30,5 +30,22 @@ for b in batches:
                 bad += 1
                 print(f"MISMATCH batch {b} {name} tile {t}: max |diff| {float((y - ref).abs().max()):.4g}")
         a.tile = 0
-    print(f"batch {b}: swept {len(eng._conv_args)} launches x {ntiles} tiles")
+    # every variant of both fused kernel families for every expand(-> reduce) launch of the plan, and its unfused form
+    import ctypes as C
+    nv_total = 0
+    for name, pair in zip(eng._er_names, eng._er_args):
+        nvar = _lib.load().hawq_conv_expand_reduce_variants(C.byref(pair.er))
+        for v in range(0, nvar + 1):
+            pair.er.tile, pair.fused = v, True
+            y = eng(x)
+            nv_total += 1
+            if not torch.equal(y, ref):
+                bad += 1
+                print(f"MISMATCH batch {b} {name} fused variant {v}: max |diff| {float((y - ref).abs().max()):.4g}")
+        pair.fused = False
+        if not torch.equal(eng(x), ref):
+            bad += 1
+            print(f"MISMATCH batch {b} {name} as separate launches")
+        pair.er.tile, pair.fused = 0, True
+    print(f"batch {b}: swept {len(eng._conv_args)} launches x {ntiles} tiles, {len(eng._er_args)} expand(-> reduce) launches x their variants ({nv_total} runs)")
 print("mismatches:", bad)
