@@ -71,8 +71,10 @@ def mobilenet_line(batch, dev, steps):
     same = bool(np.array_equal(np.rint(y[:8].cpu().numpy() / s), np.rint(y_mod.cpu().numpy() / s)))
     wall, gpu_ms, blk = timed_steps(eng, steps, 5, 1)
     return {"images_per_s": round(batch * steps / wall, 1), "gpu_ms": round(gpu_ms, 4), "gpu_ms_std": blk["std_ms"],
-            "launches": len(eng._ops), "fast_requant_launches": eng.n_fast, "autotuned_tiles": eng.tile_choice, "plan_bytes_per_image": int(eng.plan_bytes // batch),
-            "hbm_frac": round(eng.plan_bytes / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4),
+            "launches": eng.n_launches, "concurrent_sub_batches": eng.chains, "chain_timing_ms": getattr(eng, "chain_timing_ms", None),
+            "fast_requant_launches": eng.fast_requant_launches, "autotuned_tiles": eng.tile_choice,
+            "plan_bytes_per_image": int(eng.total_plan_bytes // batch),
+            "hbm_frac": round(eng.total_plan_bytes / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4),
             "plan_equals_module_path": same}
 
 

@@ -123,7 +123,10 @@ def _relu6_is_relu(s_a, s_w, m, e, q_hi) -> bool:
 class MobileNetV2Engine:
     """Callable: fp32 NCHW images on the GPU -> fp32 logits of the frozen Q_MobileNetV2 (see the module docstring)."""
 
-    def __init__(self, model, from_buffers: bool = False, use_graph: bool = True, keep_accumulators: bool = False):
+    def __init__(self, model, from_buffers: bool = False, use_graph: bool = True, keep_accumulators: bool = False, chains: int = 0):
+        """``chains``: 1 = one launch chain; 2 = the batch split into two sub-batches whose chains run on two streams inside the
+        one hipGraph (tails, prologues and dispatch gaps of one overlap the other's kernels, as in the ResNet engine); 0 = decided
+        by timing both at the first call of a batch shape (HAWQ_MBV2_CHAINS overrides)."""
         if not model.is_frozen():
             raise RuntimeError("MobileNetV2Engine needs a frozen model (freeze_model) - ranges must be fixed")
         _lib.load()
@@ -134,8 +137,19 @@ class MobileNetV2Engine:
         self.stream = torch.cuda.Stream(device=self.dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._batch = self._graph = None
-        self.taps = {}
+        self.taps, self.subs = {}, []
+        self.chains_req = 1 if keep_accumulators else max(0, int(os.environ.get("HAWQ_MBV2_CHAINS", chains)))
+        self.chains = max(1, self.chains_req)
         self._prepare()
+
+    def _spawn(self):
+        """a chain of this plan: shares the prepared parameters, owns its stream and activation buffers"""
+        sub = object.__new__(MobileNetV2Engine)
+        sub.model, sub.from_buffers, sub.keep_acc, sub.dev, sub.flags, sub.P = self.model, self.from_buffers, self.keep_acc, self.dev, self.flags, self.P
+        sub.use_graph, sub.stream = False, torch.cuda.Stream(device=self.dev)
+        sub._batch = sub._graph = None
+        sub.taps, sub.subs, sub.chains, sub.chains_req = {}, [], 1, 1
+        return sub
 
     # ------------------------------------------------------------------ host-side preparation
     def _scale(self, act):
@@ -261,16 +275,65 @@ class MobileNetV2Engine:
         self.taps[name] = (acc, (N, ho, wo, cout_p), cout)
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
 
-    def _build(self, N, H, W):
-        P, dev, sp = self.P, self.dev, self.stream.cuda_stream
+    def _time_graph(self, reps: int = 12) -> float:
+        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+        _lib.call("hawq_event_create", C.byref(e0))
+        _lib.call("hawq_event_create", C.byref(e1))
+        with torch.cuda.stream(self.stream):
+            for _ in range(2):
+                self.run_resident()
+            _lib.call("hawq_event_record", e0, self.stream.cuda_stream)
+            for _ in range(reps):
+                self.run_resident()
+            _lib.call("hawq_event_record", e1, self.stream.cuda_stream)
+        torch.cuda.synchronize(self.dev)
+        _lib.call("hawq_event_elapsed_ms", e0, e1, C.byref(ms))
+        _lib.call("hawq_event_destroy", e0)
+        _lib.call("hawq_event_destroy", e1)
+        return ms.value / reps
+
+    def _drop_graph(self):
         if self._graph is not None:
             _lib.call("hawq_graph_destroy", self._graph)
+        self._graph = None
+
+    def _build(self, N, H, W, x_view=None, logits_view=None):
+        if x_view is None and self.chains_req == 0 and self.use_graph and N >= 16:
+            timing = {}
+            for c in (1, 2):   # keep whichever chain count replays faster
+                self.chains = c
+                self._build_chains(N, H, W)
+                timing[c] = self._time_graph()
+                self._drop_graph()
+            self.chains, self.chain_timing_ms = min(timing, key=timing.get), timing
+        self._build_chains(N, H, W, x_view, logits_view)
+
+    def _build_chains(self, N, H, W, x_view=None, logits_view=None):
+        self._drop_graph()
+        if self.chains > 1 and N >= 2 * self.chains and x_view is None:
+            nout = self.P['fc']['nout']
+            self.x_in = torch.empty(N, 3, H, W, dtype=torch.float32, device=self.dev)
+            self.logits = torch.empty(N, nout, dtype=torch.float32, device=self.dev)
+            self.subs, b0 = [], 0
+            for i in range(self.chains):
+                b1 = b0 + N // self.chains + (1 if i < N % self.chains else 0)
+                sub = self._spawn()
+                sub._build_chains(b1 - b0, H, W, self.x_in[b0:b1], self.logits[b0:b1])
+                self.subs.append(sub)
+                b0 = b1
+            self._ops, self._keep, self._batch, self.taps = [], [], (N, H, W), {}
+            return
+        self.subs = []
+        self._build_one(N, H, W, x_view, logits_view)
+
+    def _build_one(self, N, H, W, x_view=None, logits_view=None):
+        P, dev, sp = self.P, self.dev, self.stream.cuda_stream
         ops, keep, self.taps, self._graph = [], [], {}, None
         self._convs, self._tuned = [], False   # hawq_conv2d argument structs of the plan (tile autotuning)
         self.n_fast = 0
         self.plan_bytes = N * 3 * H * W * 4   # bytes the plan has to move at the networks' true widths (no padding channels)
         alloc = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
-        self.x_in = alloc(N * 3 * H * W, torch.float32).view(N, 3, H, W)
+        self.x_in = x_view if x_view is not None else alloc(N * 3 * H * W, torch.float32).view(N, 3, H, W)
         init = P['init']['layer']
         if init.im2col:
             # input QuantAct (quant_modules.py:271-274) straight into the init conv's 27-value patches, one 64-byte row per output pixel
@@ -371,7 +434,7 @@ class MobileNetV2Engine:
         fc = P['fc']
         if fc['k'] != cl:
             raise RuntimeError("classifier width does not match the final block")
-        self.logits = alloc(N * fc['nout'], torch.float32).view(N, fc['nout'])
+        self.logits = logits_view if logits_view is not None else alloc(N * fc['nout'], torch.float32).view(N, fc['nout'])
         a = _lib.ConvArgs()
         a.in_, a.wgt, a.bias = qf.data_ptr(), fc['w'].data_ptr(), fc['bias'].data_ptr()
         a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = N, 1, 1, fc['k'], fc['nout_p'], 1, 1, 1, 0
@@ -422,31 +485,54 @@ class MobileNetV2Engine:
 
     @property
     def tile_choice(self):
-        return ".".join(str(a.tile) for _, a in self._convs)
+        return self.subs[0].tile_choice if self.subs else ".".join(str(a.tile) for _, a in self._convs)
+
+    @property
+    def total_plan_bytes(self):
+        return sum(sub.plan_bytes for sub in self.subs) if self.subs else self.plan_bytes
+
+    @property
+    def fast_requant_launches(self):
+        return self.subs[0].n_fast if self.subs else self.n_fast
 
     # ------------------------------------------------------------------ execution
-    def run_resident(self):
+    def _launch_all(self):
+        if self.subs:   # fork: every chain on its own stream, joined back into self.stream
+            fork = torch.cuda.Event()
+            fork.record(self.stream)
+            for sub in self.subs:
+                sub.stream.wait_event(fork)
+                sub._launch_all()
+                join = torch.cuda.Event()
+                join.record(sub.stream)
+                self.stream.wait_event(join)
+            return
         if not self._tuned and not self.keep_acc:
             for op in self._ops:   # every buffer holds valid data before launches are timed on it
                 op()
             self._autotune()
+        for op in self._ops:
+            op()
+
+    def run_resident(self):
         if self.use_graph:
             if self._graph is None:
-                for op in self._ops:   # warm-up outside capture
-                    op()
+                self._launch_all()   # warm-up (and tile tuning) outside capture
                 torch.cuda.synchronize(self.dev)
                 _lib.call("hawq_graph_begin", self.stream.cuda_stream)
                 try:
-                    for op in self._ops:
-                        op()
+                    self._launch_all()
                 finally:
                     g = C.c_void_p()
                     _lib.call("hawq_graph_end", self.stream.cuda_stream, C.byref(g))
                 self._graph = g
             _lib.call("hawq_graph_launch", self._graph, self.stream.cuda_stream)
         else:
-            for op in self._ops:
-                op()
+            self._launch_all()
+
+    @property
+    def n_launches(self):
+        return sum(len(sub._ops) for sub in self.subs) if self.subs else len(self._ops)
 
     def __call__(self, x):
         if not x.is_cuda:

@@ -330,6 +330,31 @@ def test_mobilenetv2_matches_reference_golden(scheme):
         assert np.array_equal(np.rint(y_own.cpu().numpy() / s_out), np.rint(fx["logits"] / s_out))
 
 
+def test_mobilenetv2_concurrent_sub_batches_are_bit_identical():
+    """MobileNetV2Engine may split a batch into two sub-batches whose chains run concurrently inside one hipGraph (chosen by timing
+    at batch >= 16, or forced): logits must not depend on the split (an uneven one included), nor on the per-launch tile tuning."""
+    from hawq_amd.api import build_quantized_model, calibrate
+    from hawq_amd.engine_mbv2 import MobileNetV2Engine
+    from hawq_amd.skeleton import synthetic_images
+    model = build_quantized_model("mobilenetv2_w1", "uniform8", seed=0).cuda()
+    calibrate(model, _images().cuda())
+    x = (synthetic_images(21, seed=5) * 1.2).cuda()
+    ref = MobileNetV2Engine(model, chains=1, use_graph=False)(x).clone()
+    os.environ["HAWQ_MBV2_TILES"] = "0"     # the library's heuristic tiles, no tuning
+    try:
+        assert torch.equal(MobileNetV2Engine(model, chains=1)(x), ref)
+    finally:
+        del os.environ["HAWQ_MBV2_TILES"]
+    for chains in (2, 0):
+        eng = MobileNetV2Engine(model, chains=chains)
+        assert torch.equal(eng(x), ref), chains
+        assert torch.equal(eng(x), ref), chains   # graph replay
+        if chains == 0:
+            assert eng.chains in (1, 2) and set(eng.chain_timing_ms) == {1, 2}
+        else:
+            assert len(eng.subs) == 2 and [s._batch[0] for s in eng.subs] == [11, 10]
+
+
 def _load_mobilenet_reference_state(model, fx):
     """the reference run's frozen ranges and integer checkpoint (tests/golden/net_mobilenetv2_*.npz) into `model`"""
     import hashlib
