@@ -390,3 +390,40 @@ def test_resize_coefficients_match_the_independent_restatement():
             assert abs(int(c[o].sum()) - (1 << 22)) <= len(ks)
     assert resize_crop_geometry(375, 500) == (256, 341, 16, 58) and resize_crop_geometry(500, 375) == (341, 256, 58, 16)
     assert resize_crop_geometry(256, 256) == (256, 256, 16, 16)
+
+
+def test_relu6_restated_as_relu_plus_clamp_is_exact_where_the_engine_accepts_it():
+    """hawq_amd.engine_mbv2._relu6_is_relu decides, per layer, whether `conv -> ReLU6 -> QuantAct` (q_mobilenetv2.py:66-72, the fp32
+    pipeline: x = acc * fl(S_a * S_w), min(max(x, 0), 6.0), z = round(x / S_a / S_w), RNE(z * m / 2^e), clamp) may run as
+    `RNE(max(acc, 0) * m / 2^e)` + the QuantAct's clamp.  Where it says yes the two must agree on EVERY accumulator - sampled around
+    zero, around the ReLU6 saturation point and far above it; where it says no, a differing accumulator must exist (the engine then
+    refuses the layer instead of running it)."""
+    from hawq_amd.engine_mbv2 import _relu6_is_relu
+    from hawq_amd.quant_utils import requant_table
+    f32 = np.float32
+
+    def rne(z, m, e):
+        t = z * int(m) + (1 << (e - 1))
+        q = np.floor_divide(t, 1 << e)
+        return np.where((t % (1 << e) == 0) & (q % 2 == 1), q - 1, q)
+
+    rng = np.random.default_rng(0)
+    yes = no = 0
+    for _ in range(120):
+        s_a, s_w = float(rng.uniform(0.01, 0.06)), float(rng.uniform(0.001, 0.01))
+        s_out = float(rng.uniform(1.0, 9.0)) / 127
+        m, e = requant_table(torch.tensor([s_a]), torch.tensor([s_w]), torch.tensor([s_out]), lift=False)
+        m, e = int(m[0]), int(e[0])
+        a6 = int(round(6.0 / s_a / s_w))
+        a = np.concatenate([np.arange(-50, 200), np.arange(a6 - 3000, a6 + 3000), rng.integers(0, 4 * a6, 2000)]).astype(np.int64)
+        x = np.minimum(np.maximum((a.astype(f32) * (f32(s_a) * f32(s_w))).astype(f32), f32(0)), f32(6.0))
+        z = np.rint((x / f32(s_a) / f32(s_w)).astype(np.float64)).astype(np.int64)
+        ref = np.clip(rne(z, m, e), -128, 127)
+        plan = np.clip(rne(np.maximum(a, 0), m, e), 0, 127)
+        if _relu6_is_relu(s_a, np.array([s_w]), [m], [e], 127):
+            assert np.array_equal(ref, plan)
+            yes += 1
+        else:
+            assert not np.array_equal(ref, plan)
+            no += 1
+    assert yes > 20 and no > 20
