@@ -422,6 +422,57 @@ __global__ __launch_bounds__(256) void quantize_im2col3x3s2_kernel(const float *
 }
 }  // namespace
 
+namespace {
+// the same rows from uint8 NHWC pixels: ToTensor + Normalize + the input QuantAct are one table look-up per channel
+// (lut[c][u], hawq_amd.quant_utils.input_quant_lut - the reference pipeline's own float operations, evaluated on the host)
+__global__ __launch_bounds__(256) void quantize_im2col3x3s2_u8_kernel(const uint8_t *__restrict__ x, const int8_t *__restrict__ lut, int8_t *__restrict__ out,
+                                                                      int N, int H, int W, int Ho, int Wo) {
+    __shared__ int8_t lut_s[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256 / 4; i += 256) reinterpret_cast<int *>(lut_s)[i] = reinterpret_cast<const int *>(lut)[i];
+    __syncthreads();
+    const long long total = (long long)N * Ho * Wo;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const long long r = i / Wo;
+        const int oy = (int)(r % Ho), n = (int)(r / Ho);
+        int q[28];
+        q[27] = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = 2 * oy - 1 + kh;
+            const bool rv = (unsigned)iy < (unsigned)H;
+            const int iyc = min(max(iy, 0), H - 1);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = 2 * ox - 1 + kw;
+                const bool ok = rv && (unsigned)ix < (unsigned)W;
+                const uint8_t *px = x + (((long long)n * H + iyc) * W + min(max(ix, 0), W - 1)) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) q[(kh * 3 + kw) * 3 + c] = ok ? (int)lut_s[c * 256 + px[c]] : 0;
+            }
+        }
+        v4i *dst = reinterpret_cast<v4i *>(out + i * 64);
+        v4i o0, o1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o0[k] = (int)pack4_i8(q[4 * k], q[4 * k + 1], q[4 * k + 2], q[4 * k + 3]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o1[k] = (int)pack4_i8(q[16 + 4 * k], q[17 + 4 * k], q[18 + 4 * k], q[19 + 4 * k]);
+        o1[3] = 0;
+        dst[0] = o0, dst[1] = o1, dst[2] = v4i{0, 0, 0, 0}, dst[3] = v4i{0, 0, 0, 0};
+    }
+}
+}  // namespace
+
+extern "C" int hawq_quantize_im2col3x3s2_u8(const uint8_t *x, const int8_t *lut, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, void *stream) {
+    HAWQ_REQUIRE(x && lut && out, "hawq_quantize_im2col3x3s2_u8: null pointer");
+    HAWQ_REQUIRE(C == 3, "hawq_quantize_im2col3x3s2_u8: C=%d, the 64-byte patch row is laid out for 3 input channels", C);
+    HAWQ_REQUIRE(N > 0 && H > 0 && W > 0, "hawq_quantize_im2col3x3s2_u8: bad geometry");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(quantize_im2col3x3s2_u8_kernel, dim3(grid_for((long long)N * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, lut, out, N, H, W, Ho, Wo);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int hawq_quantize_im2col3x3s2(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t q_lo,
                                          int32_t q_hi, void *stream) {
     HAWQ_REQUIRE(x && out, "hawq_quantize_im2col3x3s2: null pointer");

@@ -293,9 +293,11 @@ class MobileNetV2Engine:
         return ms.value / reps
 
     def _drop_graph(self):
-        if self._graph is not None:
-            _lib.call("hawq_graph_destroy", self._graph)
-        self._graph = None
+        for attr in ("_graph", "_graph_u8"):
+            if getattr(self, attr, None) is not None:
+                _lib.call("hawq_graph_destroy", getattr(self, attr))
+            setattr(self, attr, None)
+        self.x_u8 = None
 
     def _build(self, N, H, W, x_view=None, logits_view=None):
         if x_view is None and self.chains_req == 0 and self.use_graph and N >= 16:
@@ -339,10 +341,12 @@ class MobileNetV2Engine:
             # input QuantAct (quant_modules.py:271-274) straight into the init conv's 27-value patches, one 64-byte row per output pixel
             H0, W0 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             xq = alloc(N * H0 * W0 * 64, torch.int8)
+            self._u8_index, self._xq, self._u8_op = len(ops), xq, None   # forward_uint8 swaps this launch for the table look-up form
             ops.append(partial(_lib.call, "hawq_quantize_im2col3x3s2", self.x_in.data_ptr(), xq.data_ptr(), N, 3, H, W, P['inv_s_in'], -128, 127, sp))
             keep.append(xq)
         else:
             # input QuantAct then int8 NHWC, channels padded to 64
+            self._u8_index = None
             H0, W0 = H, W
             xq_f = alloc(N * 3 * H * W, torch.float32)
             xq = torch.zeros(N * H * W * init.cin_p, dtype=torch.int8, device=dev)
@@ -496,13 +500,13 @@ class MobileNetV2Engine:
         return self.subs[0].n_fast if self.subs else self.n_fast
 
     # ------------------------------------------------------------------ execution
-    def _launch_all(self):
+    def _launch_all(self, u8: bool = False):
         if self.subs:   # fork: every chain on its own stream, joined back into self.stream
             fork = torch.cuda.Event()
             fork.record(self.stream)
             for sub in self.subs:
                 sub.stream.wait_event(fork)
-                sub._launch_all()
+                sub._launch_all(u8)
                 join = torch.cuda.Event()
                 join.record(sub.stream)
                 self.stream.wait_event(join)
@@ -511,24 +515,72 @@ class MobileNetV2Engine:
             for op in self._ops:   # every buffer holds valid data before launches are timed on it
                 op()
             self._autotune()
-        for op in self._ops:
-            op()
+        for i, op in enumerate(self._ops):
+            if u8 and i == self._u8_index:
+                self._u8_op()
+            else:
+                op()
 
-    def run_resident(self):
+    def run_resident(self, u8: bool = False):
+        """One forward over ``self.x_in`` (or, ``u8``, over ``self.x_u8``) already resident, on ``self.stream``."""
         if self.use_graph:
-            if self._graph is None:
-                self._launch_all()   # warm-up (and tile tuning) outside capture
+            attr = "_graph_u8" if u8 else "_graph"
+            if getattr(self, attr, None) is None:
+                self._launch_all(u8)   # warm-up (and tile tuning) outside capture
                 torch.cuda.synchronize(self.dev)
                 _lib.call("hawq_graph_begin", self.stream.cuda_stream)
                 try:
-                    self._launch_all()
+                    self._launch_all(u8)
                 finally:
                     g = C.c_void_p()
                     _lib.call("hawq_graph_end", self.stream.cuda_stream, C.byref(g))
-                self._graph = g
-            _lib.call("hawq_graph_launch", self._graph, self.stream.cuda_stream)
+                setattr(self, attr, g)
+            _lib.call("hawq_graph_launch", getattr(self, attr), self.stream.cuda_stream)
         else:
-            self._launch_all()
+            self._launch_all(u8)
+
+    # ------------------------------------------------------------------ uint8 image input (quant_train.py:428-440)
+    def _ensure_u8(self, N, H, W, x_view=None, lut=None):
+        if getattr(self, "x_u8", None) is not None:
+            return
+        self.lut_dev = lut if lut is not None else torch.zeros(3 * 256, dtype=torch.int8, device=self.dev)
+        self._lut_key = None   # a fresh table buffer: the next forward_uint8 uploads its look-up table
+        self.x_u8 = x_view if x_view is not None else torch.empty(N, H, W, 3, dtype=torch.uint8, device=self.dev)
+        if self.subs:
+            b0 = 0
+            for sub in self.subs:
+                n = sub._batch[0]
+                sub._ensure_u8(n, H, W, self.x_u8[b0:b0 + n], self.lut_dev)
+                b0 += n
+            return
+        if self._u8_index is None:
+            raise NotImplementedError("uint8 input needs the im2col input quantiser (3x3 / stride 2 init conv on 3 channels)")
+        self._u8_op = partial(_lib.call, "hawq_quantize_im2col3x3s2_u8", self.x_u8.data_ptr(), self.lut_dev.data_ptr(), self._xq.data_ptr(),
+                              N, 3, H, W, self.stream.cuda_stream)
+
+    def forward_uint8(self, x_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """uint8 NHWC images [N,H,W,3] (decoder output, after resize / crop) -> fp32 logits; bit for bit what ``self(normalised
+        fp32 NCHW tensor)`` returns for the tensor the reference's data pipeline would have built (ToTensor + Normalize + the input
+        QuantAct are one table look-up, ``hawq_amd.quant_utils.input_quant_lut``)."""
+        from .quant_utils import input_quant_lut
+        if not x_u8.is_cuda or x_u8.dtype != torch.uint8 or x_u8.dim() != 4 or x_u8.shape[3] != 3:
+            raise ValueError("expected a uint8 NHWC [N,H,W,3] tensor on the MI355X")
+        N, H, W, _ = x_u8.shape
+        if self._batch != (N, H, W):
+            self._build(N, H, W)
+        self._ensure_u8(N, H, W)
+        key = (tuple(float(v) for v in mean), tuple(float(v) for v in std))
+        cur = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if getattr(self, "_lut_key", None) != key:
+                self.lut_dev.copy_(input_quant_lut(self.P['inv_s_in'], mean, std).reshape(-1).to(self.dev), non_blocking=False)
+                self._lut_key = key
+            self.x_u8.copy_(x_u8, non_blocking=True)
+            self.run_resident(u8=True)
+            out = self.logits.clone()
+        cur.wait_stream(self.stream)
+        return out
 
     @property
     def n_launches(self):
@@ -559,7 +611,8 @@ class MobileNetV2Engine:
 
     def __del__(self):
         try:
-            if self._graph is not None:
-                _lib.call("hawq_graph_destroy", self._graph)
+            for attr in ("_graph", "_graph_u8"):
+                if getattr(self, attr, None) is not None:
+                    _lib.call("hawq_graph_destroy", getattr(self, attr))
         except Exception:
             pass

@@ -273,6 +273,11 @@ int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32
 int hawq_quantize_im2col3x3s2(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t q_lo,
                               int32_t q_hi, void *stream);
 
+/* The same patch rows from uint8 NHWC images [N][H][W][3] (decoder output after resize / crop, quant_train.py:428-440): ToTensor +
+ * Normalize + the input QuantAct as one table look-up per channel, lut int8 [3][256] built on the host with the reference
+ * pipeline's own float operations (hawq_amd.quant_utils.input_quant_lut) - bit-identical to quantising the normalised fp32 tensor. */
+int hawq_quantize_im2col3x3s2_u8(const uint8_t *x, const int8_t *lut, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, void *stream);
+
 /* One separable pass of Pillow's 8-bit antialiased resampling (what torchvision's Resize(256) does to the decoded PIL image,
  * quant_train.py:428-440): uint8 HWC in / out, int32 coefficients with 22 fractional bits (hawq_amd/image.py builds them as
  * Resample.c's precompute_coeffs + normalize_coeffs_8bpc do).

@@ -355,6 +355,32 @@ def test_mobilenetv2_concurrent_sub_batches_are_bit_identical():
             assert len(eng.subs) == 2 and [s._batch[0] for s in eng.subs] == [11, 10]
 
 
+def test_mobilenetv2_uint8_input_equals_the_normalised_tensor_path():
+    """MobileNetV2Engine.forward_uint8 (hawq_quantize_im2col3x3s2_u8: ToTensor + Normalize + input QuantAct as a table look-up
+    feeding the init conv's im2col rows) == the fp32 path on the tensor the reference's pipeline builds (quant_train.py:428-440),
+    one chain and two; api.validate(uint8=True) runs on it."""
+    from hawq_amd.api import build_quantized_model, calibrate, validate
+    from hawq_amd.engine_mbv2 import MobileNetV2Engine
+    model = build_quantized_model("mobilenetv2_w1", "uniform8", seed=0).cuda()
+    calibrate(model, _images().cuda())
+    g = torch.Generator().manual_seed(7)
+    for n, chains in ((3, 1), (18, 2)):
+        xu8 = torch.randint(0, 256, (n, 224, 224, 3), dtype=torch.uint8, generator=g)
+        xu8[0, :2] = 0
+        xu8[0, 2:4] = 255
+        eng = MobileNetV2Engine(model, chains=chains)
+        for mean, std in (((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)), ((0.5, 0.4, 0.45), (0.25, 0.2, 0.3))):
+            t = xu8.permute(0, 3, 1, 2).to(torch.float32).div(255)                       # ToTensor
+            t = t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))  # Normalize
+            ref = eng(t.cuda()).clone()
+            assert torch.equal(eng.forward_uint8(xu8.cuda(), mean, std), ref), (n, chains, mean)
+            assert torch.equal(eng.forward_uint8(xu8.cuda(), mean, std), ref)   # graph replay
+        assert ref.abs().max() > 0
+    labels = model(t.cuda()).argmax(1).cpu()
+    mean, std = (0.5, 0.4, 0.45), (0.25, 0.2, 0.3)
+    assert validate(model, [(xu8, labels)], uint8=True, mean=mean, std=std) == (100.0, 100.0, 18)
+
+
 def _load_mobilenet_reference_state(model, fx):
     """the reference run's frozen ranges and integer checkpoint (tests/golden/net_mobilenetv2_*.npz) into `model`"""
     import hashlib
