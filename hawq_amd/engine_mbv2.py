@@ -2,8 +2,8 @@
 
 The module path of ``hawq_amd.q_mobilenetv2`` moves fp32 NCHW ``integer x scale`` tensors between kernels like the reference
 does.  This plan keeps integers: int8 NHWC activations between the convs of a unit, int32 NHWC for the 16-bit values that
-flow between units (MobileNetV2's units end WITHOUT an activation, so those values are signed - the uint16 residual trick
-of the ResNet plan does not apply), three launches per unit, one hipGraph per batch shape:
+flow between units and are read again (MobileNetV2's units end WITHOUT an activation, so those values are signed - the uint16
+residual format of the ResNet plan does not apply), three launches per unit, one hipGraph per batch shape:
 
     input QuantAct -> init_block 3x3/2 (+ReLU6 + quant_act_int32 + unit 1's block-input QuantAct)
     per unit:  conv1 1x1 (+ReLU6 + quant_act1) -> conv2 depthwise 3x3 (+ReLU6 + quant_act2)
@@ -25,8 +25,11 @@ Integer semantics (reference: q_mobilenetv2.py:60-93, 176-209; quant_utils.py:36
     (quant_modules.py:727-736): its logits carry float noise of the order of an ulp.  This plan returns
     ``float(acc) * fl(S_w[c] * S_a)``: identical int32 accumulators, logits within 2 ulp (tests/test_gpu_network.py).
 
-All convs run the exact general kernels (``fast_tables = 0``: any e, ties handled); the depthwise layers run
-``hawq_depthwise3x3_requant``.  This is a correct integer plan, not yet a tuned one.
+The unit-closing convs (signed carriers) run the exact general epilogue (``fast_tables = 0``: any e, ties handled; ``n_valid``
+skips the padding channels); the expansion convs run the host-proved fast requant contract; the depthwise layers run
+``hawq_depthwise3x3_requant``; the input QuantAct writes the init conv's im2col rows (fp32 or, ``forward_uint8``, uint8 images
+through a look-up table).  Every ``hawq_conv2d`` launch is tile-tuned by timing, and the batch runs as one or two concurrent
+sub-batch chains inside the one hipGraph, whichever replays faster (36.5 k -> 97 k img/s over round 3).
 """
 from __future__ import annotations
 
