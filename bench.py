@@ -75,6 +75,8 @@ def mobilenet_line(batch, dev, steps):
             "fast_requant_launches": eng.fast_requant_launches, "autotuned_tiles": eng.tile_choice,
             "plan_bytes_per_image": int(eng.total_plan_bytes // batch),
             "hbm_frac": round(eng.total_plan_bytes / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4),
+            # all 128 x 1000 logits against the CPU oracle's fixture (oracle/oracle_mbv2.py through tests/golden/make_b128.py)
+            "gpu_logits_bit_equal": golden_parity("mobilenetv2_w1", "uniform8", batch, 1, y),
             "plan_equals_module_path": same}
 
 
@@ -557,10 +559,10 @@ def main():
                 "concurrent_sub_batches": e2.chains}
             del m2, e2, x2
             torch.cuda.empty_cache()
-        # MobileNetV2 (w1, W8A8) through its own fused integer plan (hawq_amd/engine_mbv2.py).  There is no CPU
-        # oracle for this family; the check beside the number is plan vs the module-by-module path (independent kernels and
-        # fp32 glue) on the first 8 images - identical output integers (tests/test_gpu_network.py pins both to the live
-        # reference's per-layer digests)
+        # MobileNetV2 (w1, W8A8) through its own fused integer plan (hawq_amd/engine_mbv2.py).  Checks beside the
+        # number: all 128 x 1000 logits against the CPU oracle's fixture, and plan vs the module-by-module path (independent
+        # kernels and fp32 glue) on the first 8 images - identical output integers (tests/test_gpu_network.py pins both to the
+        # live reference's per-layer digests)
         extra["mobilenetv2_w1_uniform8_b%d" % args.batch] = mobilenet_line(args.batch, dev, n2)
         # what ONE GPU runs when the batch of 128 is sharded over 2 / 4 / 8 ranks (strong scaling):
         # the first 64 / 32 / 16 images of the headline workload, same engine configuration

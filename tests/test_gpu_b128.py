@@ -150,3 +150,32 @@ def test_uint16_residual_overflow_heals_itself(arch, scheme):
     t = t.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))
     ref_u8, _ = oracle.forward_int(st, t.numpy())
     assert np.array_equal(eng.forward_uint8(xu8.cuda(), mean, std).cpu().numpy(), ref_u8)
+
+
+def test_mobilenetv2_benchmarked_configuration_is_bit_exact_at_batch_128():
+    """bench.py's MobileNetV2 line (bench.mobilenet_line: weights seed 0, ranges calibrated ON THE DEVICE on 8 images, 128 images,
+    tile-tuned plan, chain count chosen by timing, hipGraph) against oracle/oracle_mbv2.py's fixture
+    (tests/golden/b128_mobilenetv2_w1_uniform8.npz, make_b128.py: the CPU restatement - pinned to the live reference by
+    tests/test_oracle_vs_golden.py - calibrates itself on the same 8 images and keeps ReLU6 on the fp32 tensors): all 128 x 1000
+    logits and top-1 equal; one slice of 16 images is recomputed by the oracle on this box, with the
+    16-bit outputs of all 17 units compared through the module path's frozen ranges."""
+    from hawq_amd.api import build_quantized_model, calibrate
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import oracle_mbv2
+    fx = H.load("b128_mobilenetv2_w1_uniform8.npz")
+    model = build_quantized_model("mobilenetv2_w1", "uniform8", seed=0).cuda()
+    calibrate(model, synthetic_images(int(fx["calib"]), seed=0).cuda())
+    x = synthetic_images(128, seed=int(fx["seed"]))
+    assert H.sha(x.numpy()) == str(fx["input_sha"])
+    eng = model.engine()
+    y = eng(x.cuda()).cpu().numpy()
+    assert eng.use_graph and eng.chains in (1, 2) and set(eng.chain_timing_ms) == {1, 2}
+    assert np.array_equal(y, fx["logits"]), f"{int((y != fx['logits']).any(1).sum())} of 128 images differ"
+    assert np.array_equal(y.argmax(1), fx["top1"])
+    assert np.array_equal(eng(x.cuda()).cpu().numpy(), y)   # graph replay
+    # the oracle on this box, fed with the ranges the DEVICE calibration froze: same logits, same unit outputs as the fixture's slice
+    s = int(fx["slice"])
+    st = oracle_mbv2.extract_float_state(model)
+    ref, tr = oracle_mbv2.forward_int(st, x[128 - s:].numpy())
+    assert np.array_equal(ref, fx["logits"][128 - s:])
+    assert [H.sha(tr[str(n)].astype(np.int32)) for n in fx["residual_names"]] == [str(v) for v in fx["residual_sha"][-1]]

@@ -180,6 +180,48 @@ def test_network_forward_matches_reference(arch, scheme):
     _check_oracle_against_fixture(arch, scheme, H.net_fixture(arch, scheme))
 
 
+@pytest.mark.parametrize("scheme", ["uniform8", "uniform4", "bops_0.5"])
+def test_mobilenetv2_oracle_matches_the_live_reference_fixture(scheme):
+    """oracle/oracle_mbv2.py (the CPU restatement of the frozen Q_MobileNetV2 forward, ReLU6 kept on the fp32 tensor as the reference
+    has it) against the fixture the UNMODIFIED reference wrote (tests/golden/make_kat_extra.py --mobilenet): on its frozen ranges
+    and integer checkpoint, the int32 accumulators of ALL 54 convs (17 depthwise, the classifier) and the integers behind EVERY
+    QuantAct have the recorded digests; the oracle's own weight preparation reproduces the reference's integer weights (SHA-256)
+    after the recorded patches; logits equal the reference's up to the float noise of its fp32 classifier conv, same top-1."""
+    import hashlib
+    import torch
+    from hawq_amd.api import build_quantized_model
+    from hawq_amd.quant_modules import QuantAct
+    from hawq_amd.skeleton import synthetic_images
+    from oracle import oracle_mbv2
+    fx = H.load(f"net_mobilenetv2_w1_{scheme}_b2.npz")
+    model = build_quantized_model("mobilenetv2_w1", scheme, seed=0)
+    acts = [(n, m) for n, m in model.named_modules() if isinstance(m, QuantAct)]
+    assert [n for n, _ in acts] == [str(n) for n in fx["act_names"]]
+    for i, (_, m) in enumerate(acts):
+        m.x_min.fill_(float(fx["act_x_min"][i])), m.x_max.fill_(float(fx["act_x_max"][i]))
+    st = oracle_mbv2.extract_float_state(model)
+    ckpt, off = {}, 0
+    for li, n in enumerate(str(v) for v in fx["conv_names"]):
+        co = dict(model.named_modules())[n].conv.out_channels if n != "output" else model.output.out_channels
+        ckpt[n] = dict(scale=fx["conv_scale"][off:off + co], bias=fx["conv_bias"][off:off + co].astype(np.int64),
+                       wpatch=[(int(idx), int(val)) for l, idx, val in fx["conv_wpatch"] if l == li])
+        off += co
+    x = synthetic_images(2, seed=0).numpy()
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(fx["input_sha"])
+    logits, tr = oracle_mbv2.forward_int(st, x, ckpt)
+    for li, n in enumerate(str(v) for v in fx["conv_names"]):
+        assert hashlib.sha256(np.ascontiguousarray(tr[n + ".weight_integer"].astype(np.int8)).tobytes()).hexdigest() == str(fx["conv_wsha"][li]), n
+        assert np.array_equal(H.digest(tr[n + ".acc"]), fx["conv_accdigest"][li]), n
+    for ai, n in enumerate(str(v) for v in fx["act_names"]):
+        assert np.array_equal(H.digest(tr[n + ".q"]), fx["act_outdigest"][ai]), n
+        assert int(np.abs(tr[n + ".q"]).max()) == int(fx["act_outmax"][ai]), n
+    ref = fx["logits"]
+    assert np.array_equal(logits.argmax(1), fx["top1"])
+    s = (tr["output.conv_scaling_factor"].astype(np.float64) * float(fx["act_scale"][-1])).reshape(1, -1)
+    assert np.array_equal(np.rint(logits / s), np.rint(ref / s))        # the same integers ...
+    assert np.abs(logits - ref).max() <= 2 * np.spacing(np.abs(ref).max())   # ... within the reference's own float noise
+
+
 def _all_schedules():
     from hawq_amd.bit_schedules import bit_config_dict
     out = []
