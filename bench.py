@@ -71,7 +71,7 @@ def mobilenet_line(batch, dev, steps):
     same = bool(np.array_equal(np.rint(y[:8].cpu().numpy() / s), np.rint(y_mod.cpu().numpy() / s)))
     wall, gpu_ms, blk = timed_steps(eng, steps, 5, 1)
     return {"images_per_s": round(batch * steps / wall, 1), "gpu_ms": round(gpu_ms, 4), "gpu_ms_std": blk["std_ms"],
-            "launches": eng.n_launches, "concurrent_sub_batches": eng.chains, "chain_timing_ms": getattr(eng, "chain_timing_ms", None),
+            "launches": eng.n_launches, "concurrent_sub_batches": eng.chains, "chain_timing_ms": {str(k): round(v, 4) for k, v in getattr(eng, "chain_timing_ms", {}).items()} or None,
             "fast_requant_launches": eng.fast_requant_launches, "autotuned_tiles": eng.tile_choice,
             "plan_bytes_per_image": int(eng.total_plan_bytes // batch),
             "hbm_frac": round(eng.total_plan_bytes / (gpu_ms * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4),
