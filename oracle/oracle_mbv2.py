@@ -45,7 +45,7 @@ def depthwise3x3(x, w, bias, stride):
 def extract_float_state(q):
     """float parameters, bit widths, modes and frozen ranges of a Q_MobileNetV2 (the reference's or hawq_amd's: same attribute
     names); no integers are taken from the model"""
-    act, tn = O.extract_float_state.__globals__["_to_np"], None
+    act = O._to_np
 
     def a(m):
         return dict(bits=int(m.activation_bit), mode=str(m.quant_mode), x_min=act(m.x_min).astype(f32), x_max=act(m.x_max).astype(f32))
