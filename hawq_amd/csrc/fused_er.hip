@@ -487,6 +487,9 @@ int er_variant(const hawq_expand_reduce_args *a) {
 // wave-private variants (fused_wp.hip): numbered after the variants of this file; they also take reduce.wgt == NULL
 int wp_num_variants(const hawq_expand_reduce_args *a);
 int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream);
+// software-pipelined pair variants (fused_er2.hip): numbered after the wave-private ones
+int er2_num_variants(const hawq_expand_reduce_args *a);
+int er2_launch(const hawq_expand_reduce_args *a, int nth, void *stream);
 
 namespace {
 int er_count(const hawq_expand_reduce_args *a) {   // variants of THIS file that take the pair
@@ -502,12 +505,13 @@ int er_count(const hawq_expand_reduce_args *a) {   // variants of THIS file that
 
 extern "C" int hawq_conv_expand_reduce_variants(const hawq_expand_reduce_args *a) {
     if (!a) return 0;
-    return er_count(a) + wp_num_variants(a);
+    return er_count(a) + wp_num_variants(a) + er2_num_variants(a);
 }
 
 extern "C" int hawq_conv_expand_reduce(const hawq_expand_reduce_args *a, void *stream) {
     HAWQ_REQUIRE(a != nullptr, "hawq_conv_expand_reduce: null args");
-    const int n_er = er_count(a);
+    const int n_er = er_count(a), n_wp = wp_num_variants(a);
+    if (a->tile > n_er + n_wp) return er2_launch(a, a->tile - n_er - n_wp, stream);
     if (a->tile > n_er || (a->tile == 0 && n_er == 0)) return wp_launch(a, a->tile == 0 ? 1 : a->tile - n_er, stream);
     const int v = er_variant(a);
     HAWQ_REQUIRE(v >= 0, "hawq_conv_expand_reduce: this pair of layers cannot be fused (need 1x1/stride-1 int8 fast-contract convs, "

@@ -9,7 +9,10 @@ from hawq_amd.quant_utils import requant_table
 lib.load()
 rng = np.random.default_rng(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+ONLY = int(os.environ.get("ERPROBE_ONLY", 0))   # only the shape with this feature-map size, and only its fused variants (PMC runs)
 for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (7, 512, 2048)):
+    if ONLY and h != ONLY:
+        continue
     M = N * h * h
     x2 = torch.from_numpy(rng.integers(0, 128, (M, c)).astype(np.int8)).cuda()
     w3 = rng.integers(-127, 128, (c3, c, 1, 1)).astype(np.int64); b3 = rng.integers(-2000, 2000, c3).astype(np.int64)
@@ -43,7 +46,7 @@ for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (7, 512, 2048
         e1_.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1_) / reps * 1e3
     sp = torch.cuda.current_stream().cuda_stream
-    if not os.environ.get("HAWQ_DBG"):
+    if not os.environ.get("HAWQ_DBG") and not ONLY:
         # the same two layers as separate hawq_conv2d launches (best tile each), then the expand conv alone on the wave-private kernel
         qbuf = torch.zeros(M * c3, dtype=torch.uint8, device='cuda')
         ex.out_q = qbuf.data_ptr()
