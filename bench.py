@@ -36,21 +36,67 @@ sys.path.insert(0, ROOT)
 COPY_CEILING_GBS = 6290.0   # measured float4 copy rate of the part (MI355X_MICROARCH.md): what a plan's byte floor is priced at
 
 
-def setup_workload(arch, scheme, batch, dev, seed, shard=None):
+class Plans:
+    """Recorded plans by workload key (``<arch>_<scheme>_b<images the engine sees>``): ``profiles/plans.json`` by default, so that
+    the default bench REPLAYS the committed tiles / fused variants / chain count instead of re-tuning (two tuning passes differ
+    by +-2 %, more than most kernel changes - VERDICT r3 #5 / #11) and the committed PMC traffic belongs to the plan that is timed.
+    ``--retune`` ignores the file; ``--save-plan`` writes the plans this run used or tuned."""
+
+    def __init__(self, path, retune):
+        self.path, self.loaded, self.used = path, {}, {}
+        if path and not retune and os.path.isfile(path):
+            with open(path) as f:
+                self.loaded = json.load(f)
+
+    def get(self, key):
+        pl = self.loaded.get(key)
+        return dict(pl, source=f"replayed {os.path.relpath(self.path, ROOT)} (tuned at git head {pl.get('git_head', '?')})") if pl else None
+
+    def record(self, key, eng):
+        pl = eng.export_plan()
+        pl["git_head"] = self.loaded.get(key, {}).get("git_head") if eng.plan_source.startswith("replayed") else os.environ.get("GRAFT_HEAD", "unknown")
+        self.used[key] = pl
+
+    def save(self, path):
+        merged = dict(self.loaded)
+        merged.update(self.used)
+        with open(path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
+
+
+def setup_workload(arch, scheme, batch, dev, seed, shard=None, plans=None, model=None, share=False):
     """Synthetic weights (seed 0), ranges calibrated on 8 synthetic images, `batch` synthetic images (seed);
-    ``shard = (lo, hi)`` keeps only that slice of the batch (strong scaling: this rank's images)."""
+    ``shard = (lo, hi)`` keeps only that slice of the batch (strong scaling: this rank's images).  ``plans``: replay the recorded plan
+    of this workload if there is one.  ``share`` (N > 1): rank 0's plan - recorded or tuned just now - is broadcast and every other
+    rank replays it (hawq_amd.dist.share_plan), so that all ranks run ONE plan and only one rank pays for tuning."""
+    import torch.distributed as dist
     from hawq_amd.api import build_quantized_resnet, calibrate
+    from hawq_amd.dist import share_plan
     from hawq_amd.engine import IntegerEngine
     from hawq_amd.skeleton import synthetic_images
 
-    model = build_quantized_resnet(arch, scheme, seed=0).to(dev)
-    calibrate(model, synthetic_images(8, seed=0).to(dev))
-    eng = IntegerEngine(model, use_graph=True)
+    if model is None:
+        model = build_quantized_resnet(arch, scheme, seed=0).to(dev)
+        calibrate(model, synthetic_images(8, seed=0).to(dev))
     x = synthetic_images(batch, seed=seed)
     if shard is not None:
         x = x[shard[0]:shard[1]]
     x = x.to(dev)
-    eng(x)  # allocate, autotune, warm up, capture the hipGraph
+    key = f"{arch}_{scheme}_b{x.shape[0]}"
+    plan = plans.get(key) if plans is not None else None
+    leader = not share or not dist.is_initialized() or dist.get_rank() == 0
+    eng = None
+    if leader:
+        eng = IntegerEngine(model, use_graph=True, plan=plan)
+        eng(x)  # allocate, replay the plan or autotune, warm up, capture the hipGraph
+        plan = dict(eng.export_plan(), source=eng.plan_source if eng.plan_source.startswith("replayed") else "tuned on rank 0 in this run")
+    if share and dist.is_initialized():
+        plan = share_plan(plan if leader else None)
+        if not leader:
+            eng = IntegerEngine(model, use_graph=True, plan=plan)
+            eng(x)
+    if plans is not None:
+        plans.record(key, eng)
     return model, eng, x
 
 
@@ -301,7 +347,8 @@ def spawn_ranks(n):
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+    # N ranks each opening an all-core OpenMP pool oversubscribe the host while the models are built and calibrated: share the cores
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -309,11 +356,15 @@ def dry_main(args, rank, world):
     """The N > 1 plumbing on CPU: gloo process group, stand-in forward (per-image independent, like the frozen network),
     weak and strong decomposition, gather through hawq_amd.dist.gather_logits, MAX-over-ranks clock, one JSON line."""
     import torch.distributed as dist
-    from hawq_amd.dist import gather_logits, shard_bounds
+    from hawq_amd.dist import gather_logits, plans_identical, shard_bounds, share_plan
     dist.init_process_group("gloo")
     world_seen = dist.get_world_size()
     if world_seen != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has {world_seen} ranks")
+    # every rank "tunes" something else (as independent tuning passes do); after share_plan all hold rank 0's plan
+    own = {"batch": args.batch, "chains": 2, "tiles": ".".join(str(3 + rank + i) for i in range(5)), "fused_variants": f"{1 + rank}.0"}
+    plan = share_plan(own)
+    same_plan = plans_identical(plan)
     w = torch.randn(3 * 8 * 8, 10, generator=torch.Generator().manual_seed(0))
 
     def fwd(x):
@@ -348,7 +399,8 @@ def dry_main(args, rank, world):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": res[args.scaling]["ms_per_step"],
                           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
                           "data": "dry-spawn: CPU stand-in forward on gloo (launch / shard / gather plumbing only, not a measurement)",
-                          "config": {"workload": "dry_spawn_stub", "ranks_seen": world_seen, "backend": "gloo"},
+                          "config": {"workload": "dry_spawn_stub", "ranks_seen": world_seen, "backend": "gloo", "plan": plan,
+                                     "plan_identical_on_all_ranks": same_plan, "plan_is_rank0s": plan["tiles"] == "3.4.5.6.7"},
                           "weak": res["weak"], "strong": res["strong"]}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -367,6 +419,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-op", default=None, help="write a per-launch roofline table (markdown) to this file")
     ap.add_argument("--dry-spawn", action="store_true", help="CPU / gloo stand-in forward: exercises the N > 1 launch, shard, gather and report path")
+    ap.add_argument("--plan", default=os.path.join(ROOT, "profiles", "plans.json"),
+                    help="recorded plans by workload (replayed instead of tuning when the workload has an entry)")
+    ap.add_argument("--retune", action="store_true", help="ignore the recorded plans: tune every engine in this run")
+    ap.add_argument("--save-plan", default=None, help="write the plans this run used / tuned to this file")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="images of the benchmarked batch the CPU baseline times")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -406,9 +463,12 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         return bool(f.item())
 
+    plans = Plans(args.plan, args.retune)
     # ---- weak: every rank its own batch (rank 0's is the fixture workload)
     seed = 1 + rank
-    model, eng, x = setup_workload(args.arch, args.scheme, args.batch, dev, seed=seed)
+    model, eng, x = setup_workload(args.arch, args.scheme, args.batch, dev, seed=seed, plans=plans, share=world > 1)
+    from hawq_amd.dist import plans_identical
+    same_plan = plans_identical(eng.export_plan())
     local_batch = args.batch
     wall, gpu_ms, blocks = timed_steps(eng, args.steps, args.warmup, world)
     overflow = eng.overflowed()
@@ -418,7 +478,9 @@ def main():
     # ---- strong (N > 1 only): ONE batch of `batch` images, rank r evaluates images shard_bounds(batch, r, N)
     if world > 1:
         lo, hi = shard_bounds(args.batch, rank, world)
-        m2, e2, x2 = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1, shard=(lo, hi))
+        # the SAME model object (built and calibrated once), a second engine for the shard's batch shape; one shared plan again
+        m2, e2, x2 = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1, shard=(lo, hi), plans=plans, model=model, share=True)
+        same_plan = same_plan and plans_identical(e2.export_plan())
         w2, g2, b2 = timed_steps(e2, args.steps, args.warmup, world, batch_total=args.batch)
         p2 = all_ranks(golden_parity(args.arch, args.scheme, args.batch, 1, e2.logits, lo))
         runs["strong"] = dict(value=round(args.batch * args.steps / w2, 1), ms_per_step=round(w2 / args.steps * 1e3, 4),
@@ -470,7 +532,9 @@ def main():
                        "plan_trials_ms": getattr(eng, "plan_trials_ms", None),
                        "chain_timing_ms": {str(k): round(v, 4) for k, v in getattr(eng, "chain_timing_ms", {}).items()},
                        "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(eng, "er_split_tiles", {}).values()),
-                       "concurrent_sub_batches": eng.chains},
+                       "concurrent_sub_batches": eng.chains,
+                       # where the plan came from (profiles/plans.json replayed, or tuned here) and, N > 1, whether every rank runs it
+                       "plan_source": eng.plan_source, "plan_identical_on_all_ranks": same_plan},
             # all logits of rank 0's images against the CPU oracle's golden logits of the same workload
             "parity": {"gpu_logits_bit_equal_oracle": parity, "images_compared": local_batch if parity is not None else 0,
                        "fixture": f"tests/golden/b128_{args.arch}_{args.scheme}.npz"},
@@ -522,7 +586,7 @@ def main():
             if args.per_op:
                 write_per_op(args.per_op, ops, rows, nb)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, x, eng.logits)
+            out["cpu_baseline"] = cpu_baseline(model, x, eng.logits, sample=args.cpu_sample)
         else:
             out["cpu_baseline"] = None
     if not args.no_extra and world == 1 and rank == 0:
@@ -549,14 +613,14 @@ def main():
         for arch, scheme in (("resnet50", "uniform4"), ("resnet50", "bops_0.5"), ("resnet18", "uniform8")):
             if (arch, scheme) == (args.arch, args.scheme):
                 continue
-            m2, e2, x2 = setup_workload(arch, scheme, args.batch, dev, seed=1)
+            m2, e2, x2 = setup_workload(arch, scheme, args.batch, dev, seed=1, plans=plans)
             w2, g2, b2 = timed_steps(e2, n2, 5, 1)
             alg2 = roofline.algorithmic_bytes(arch, scheme, args.batch)
             extra[f"{arch}_{scheme}_b{args.batch}"] = {
                 "images_per_s": round(args.batch * n2 / w2, 1), "gpu_ms": round(g2, 4), "gpu_ms_std": b2["std_ms"],
                 "hbm_frac": round(alg2 / (g2 * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 4), "overflow": e2.overflowed(),
                 "gpu_logits_bit_equal": golden_parity(arch, scheme, args.batch, 1, e2.logits),
-                "concurrent_sub_batches": e2.chains}
+                "concurrent_sub_batches": e2.chains, "plan_source": e2.plan_source}
             del m2, e2, x2
             torch.cuda.empty_cache()
         # MobileNetV2 (w1, W8A8) through its own fused integer plan (hawq_amd/engine_mbv2.py).  Checks beside the
@@ -568,7 +632,7 @@ def main():
         # the first 64 / 32 / 16 images of the headline workload, same engine configuration
         if args.batch == 128:
             for nb in (64, 32, 16):
-                m2, e2, x2 = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1, shard=(0, nb))
+                m2, e2, x2 = setup_workload(args.arch, args.scheme, args.batch, dev, seed=1, shard=(0, nb), plans=plans)
                 w2, g2, b2 = timed_steps(e2, n2, 5, 1)
                 extra[f"{args.arch}_{args.scheme}_shard_b{nb}"] = {
                     "images_per_s": round(nb * n2 / w2, 1), "gpu_ms": round(g2, 4), "gpu_ms_std": b2["std_ms"],
@@ -577,6 +641,8 @@ def main():
                 del m2, e2, x2
                 torch.cuda.empty_cache()
         out["extra"] = extra
+    if args.save_plan and rank == 0:
+        plans.save(args.save_plan)
     if world > 1:
         with _stdout_to_stderr():
             dist.barrier()

@@ -93,6 +93,11 @@ class HawqLibraryError(RuntimeError):
     pass
 
 
+def library_path() -> str:
+    """Path of the shared library this process loads (the in-tree build unless HAWQ_LIB names another one)."""
+    return LIB_PATH
+
+
 def load():
     """Load the HIP library or raise - never degrade to a CPU path."""
     global _lib

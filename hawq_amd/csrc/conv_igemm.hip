@@ -642,21 +642,26 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
         const int lch = wave_c * (C::CT * 32) + c * 32 + h * 16;  // tile-local first channel of this lane
-        v4i rin[C::PT][2];
+        // Two accumulator sets (DUAL) leave no room to keep every pixel tile's packed outputs live: walk the pixel tiles one at a
+        // time there (the channel constants are re-read from LDS).  The same holds for the RESIDUAL epilogue of a kernel that must fit
+        // 4 waves per SIMD (<= 128 registers: the 16-wave band kernels, the 3x3 + residual launches of ResNet18/34): with both pixel
+        // tiles live it held 2 x (8 residual + 8 packed residual + 4 packed q) registers beside 64 accumulators and spilled 88-160
+        // of them (round 4: found by the scratch check of tests/test_host_logic.py).
+        constexpr int WPS = (C::NT / 256 > C::MINB) ? C::NT / 256 : C::MINB;   // waves per SIMD the kernel is built for
+        constexpr int QPASS = (DUAL || (RES && WPS >= 4)) ? C::PT : 1, QPER = C::PT / QPASS;
+#pragma unroll
+        for (int qp = 0; qp < QPASS; ++qp) {
+        v4i rin[C::PT][2];             // old residual values of this pass's pixel tiles (32 bytes per lane and tile)
         if constexpr (RES && !DUAL) {
 #pragma unroll
-            for (int q = 0; q < C::PT; ++q) {
+            for (int qq = 0; qq < QPER; ++qq) {
+                const int q = qp * QPER + qq;
                 const int row = lrow0 + q * 32;
                 const char *base = res_tile + row * (S::RCPR * 16);
                 rin[q][0] = *reinterpret_cast<const v4i *>(base + (((lch >> 3) ^ S::rsw(row)) << 4));
                 rin[q][1] = *reinterpret_cast<const v4i *>(base + ((((lch >> 3) + 1) ^ S::rsw(row)) << 4));
             }
         }
-        // Two accumulator sets (DUAL) leave no room to keep every pixel tile's packed outputs live:
-        // walk the pixel tiles one at a time there (the channel constants are re-read from L1).
-        constexpr int QPASS = DUAL ? C::PT : 1, QPER = C::PT / QPASS;
-#pragma unroll
-        for (int qp = 0; qp < QPASS; ++qp) {
         int qpack[QPER][4];            // 16 x int8, or 2 dwords of hawq4 in [0..1]
         int rpack[QPER][RES ? 8 : 1];  // 16 x uint16
 #pragma unroll

@@ -374,21 +374,20 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_pipelined_kernel
 }
 
 // (C = 256 with 8 producers would need 16 waves at <= 128 registers: the 64 GEMM2 accumulators + 16 of GEMM1 leave too few - 184 spills)
-using P256B = E2Cfg<256, 4, 4, 3>;   // stage 3: 128 pixels, 8 compute + 4 producer waves, 146 KiB: one workgroup per CU, 162-168 registers
+// scheduling groups (SG): pinning GEMM2's MFMAs after every channel group, after every second one or leaving them to the compiler
+// measured the same (34.8 / 34.8 / 36.4 us at batch 64: the kernel is VALU-bound, profiles/r04_pair_kernels_valu_bound.md); SG = 2 is the
+// form of C = 256 that allocates without a spill
+using P256B = E2Cfg<256, 4, 4, 3, 2>;   // stage 3: 128 pixels, 8 compute + 4 producer waves, 146 KiB: one workgroup per CU, 162-168 registers
 using P128A = E2Cfg<128, 4, 8, 4>;   // stage 2: 128 pixels, 8 + 8 waves, 98 KiB
 using P128B = E2Cfg<128, 2, 4, 4>;   //          64 pixels, 4 + 4 waves, 66 KiB: two workgroups per CU
 using P64A = E2Cfg<64, 4, 4, 3>;     // stage 1: 128 pixels, 8 + 4 waves, 74 KiB
-using P256B2 = E2Cfg<256, 4, 4, 3, 2>;
-using P256B0 = E2Cfg<256, 4, 4, 3, 0>;
-using P128A2 = E2Cfg<128, 4, 8, 4, 2>;
-using P128A0 = E2Cfg<128, 4, 8, 4, 0>;
-constexpr int NUM_E2 = 8;
+constexpr int NUM_E2 = 4;
 
 typedef void (*E2Fn)(const E2P);
 struct E2Info { E2Fn fn[5]; int c, bm, nt, lds; };   // fn: {general, exact-tie, per-channel k all zero, + next-QuantAct k zero, only the latter}
 #define E2_ENTRY(F) {{expand_reduce_pipelined_kernel<F, false>, expand_reduce_pipelined_kernel<F, true>, expand_reduce_pipelined_kernel<F, false, true>, \
                       expand_reduce_pipelined_kernel<F, false, true, true>, expand_reduce_pipelined_kernel<F, false, false, true>}, F::C, F::BM, F::NT, F::LDS_BYTES}
-const E2Info kE2[NUM_E2] = {E2_ENTRY(P256B), E2_ENTRY(P128A), E2_ENTRY(P128B), E2_ENTRY(P64A), E2_ENTRY(P256B2), E2_ENTRY(P256B0), E2_ENTRY(P128A2), E2_ENTRY(P128A0)};
+const E2Info kE2[NUM_E2] = {E2_ENTRY(P256B), E2_ENTRY(P128A), E2_ENTRY(P128B), E2_ENTRY(P64A)};
 
 bool e2_conv_ok(const hawq_conv_args &a) {
     return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 && !a.in2 && !a.in_planar;

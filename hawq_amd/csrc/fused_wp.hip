@@ -375,12 +375,14 @@ using W128 = WPCfg<128, 4, true, 2>;     // stage 2: 34 KiB
 using W128B = WPCfg<128, 8, true, 2>;
 using W256 = WPCfg<256, 4, true, 1>;     // stage 3: 82 KiB; one wave per SIMD (> 256 registers): the 2-wave allocation spilled, and a spill
                                          // reload is a vmcnt(0) wait in the middle of the LDS-DMA issue sequence
-using W256B = WPCfg<256, 8, true, 2>;
+// (a 256-pixel, two-waves-per-SIMD form of the pair, WPCfg<256, 8, true, 2>, reloaded three spilled registers inside its slice loop - a
+// scratch_load with its s_waitcnt vmcnt(0) in the middle of the LDS-DMA issue sequence - and was the slowest variant of every pair (74-81 us
+// against 26-43): removed in round 4, tests/test_host_logic.py::test_shipped_kernels_do_not_spill keeps such a kernel from shipping again)
 using N64 = WPCfg<64, 4, false, 4>;      // expand conv alone (last unit of a stage): 10 KiB
 using N128 = WPCfg<128, 4, false, 3>;
 using N256 = WPCfg<256, 4, false, 3>;
 using N512 = WPCfg<512, 4, false, 2>;    // stage 4: 66 KiB; gridDim.y splits the C3 / 64 slices
-const WPInfo kWP[] = {WP_ENTRY(W64, 1), WP_ENTRY(W64B, 1), WP_ENTRY(W128, 1), WP_ENTRY(W128B, 1), WP_ENTRY(W256, 1), WP_ENTRY(W256B, 1),
+const WPInfo kWP[] = {WP_ENTRY(W64, 1), WP_ENTRY(W64B, 1), WP_ENTRY(W128, 1), WP_ENTRY(W128B, 1), WP_ENTRY(W256, 1),
                       WP_ENTRY(N64, 1), WP_ENTRY(N128, 1), WP_ENTRY(N256, 1), WP_ENTRY(N256, 2), WP_ENTRY(N256, 4),
                       WP_ENTRY(N512, 1), WP_ENTRY(N512, 2), WP_ENTRY(N512, 4), WP_ENTRY(N512, 8)};
 constexpr int NUM_WP = sizeof(kWP) / sizeof(kWP[0]);

@@ -64,6 +64,10 @@ class _OpList(list):
         super().append(fn)
 
 
+class StalePlan(ValueError):
+    """A recorded plan does not fit the launch list / kernel inventory of this build: the engine falls back to tuning."""
+
+
 class _FusedPair:
     """One entry of the launch list that covers TWO layers - the expand conv (+ residual epilogue) of unit i and the reduce
     conv of unit i+1 - either as one hawq_conv_expand_reduce launch or as two hawq_conv2d launches, whichever the
@@ -123,11 +127,12 @@ class IntegerEngine:
 
     def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
                  keep_accumulators: bool = False, fast: bool = True, autotune: bool = True, chains: int = 0,
-                 _parent=None):
+                 plan=None, _parent=None):
         if _parent is not None:  # a chain of a multi-chain engine: shares parameters, owns stream + buffers
             self.__dict__.update({k: v for k, v in _parent.__dict__.items()
                                   if k in ("model", "dev", "res_bits", "from_buffers", "keep_acc", "fast", "autotune",
-                                           "flags", "P", "planar", "fuse_stages")})
+                                           "flags", "P", "planar", "fuse_stages", "plan")})
+            self._plan_on = False
             self.use_graph, self.chains, self.subs = False, 1, []
             self.stream = torch.cuda.Stream(device=self.dev)
             self.tile_choice, self.er_choice = {}, {}
@@ -158,6 +163,11 @@ class IntegerEngine:
         # timing the captured graph once per batch shape (HAWQ_CHAINS overrides).
         self.chains_req = 1 if keep_accumulators else max(0, int(os.environ.get("HAWQ_CHAINS", chains)))
         self.chains = max(1, self.chains_req)
+        # a recorded plan (export_plan(): chain count, tile id of every conv launch, fused variant of every expand(-> reduce) launch)
+        # for ONE batch shape: that shape is built by replaying it - no timing at all -, any other shape is tuned as usual.  What
+        # bench.py --plan and the multi-GPU path (rank 0 tunes, every rank replays: hawq_amd.dist.share_plan) hand over.
+        self.plan = dict(plan) if plan else None
+        self.plan_source = "tuned in this process"
         self.subs = []
         self.stream = torch.cuda.Stream(device=self.dev)
         self.flags = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -409,6 +419,24 @@ class IntegerEngine:
     def _build(self, N, H, W, x_view=None, logits_view=None):
         """Allocate activation buffers for batch N and record the launch list (choosing the chain count first
         when it was left open)."""
+        if x_view is None:
+            self._plan_on = bool(self.plan) and int(self.plan.get("batch", -1)) == N and not self.keep_acc
+        if x_view is None and self._plan_on:
+            try:
+                if int(self.plan.get("num_conv_tiles", -1)) != int(_lib.load().hawq_conv2d_num_tiles()):
+                    raise StalePlan("recorded for a library with another tile inventory")
+                self.chains = max(1, int(self.plan["chains"]))
+                self._build_chains(N, H, W, x_view, logits_view)
+                names = self.plan.get("conv_launches")
+                if names is not None and list(names) != list(self.tile_choice.keys()):
+                    raise StalePlan("recorded for another launch list (other network, schedule or storage rule)")
+                self.plan_source = self.plan.get("source", "replayed a recorded plan")
+                return
+            except StalePlan as exc:
+                print(f"[hawq_amd] recorded plan ignored ({exc}); tuning instead", file=sys.stderr)
+                self._plan_on = False
+                self.chains = max(1, self.chains_req)
+                self.tile_choice, self.er_choice = {}, {}
         if x_view is None and getattr(self, "chains_req", 1) == 0 and self.use_graph and self.autotune:
             timing, plans = {}, {}
             # small batches (what one GPU sees when 128 images are sharded over 4 / 8 ranks) launch fewer workgroups
@@ -440,6 +468,30 @@ class IntegerEngine:
                 self.plan_trials_ms = tuple(round(t, 4) for t in times)
             return
         self._build_chains(N, H, W, x_view, logits_view)
+
+    def _fixed(self, key):
+        """Recorded choice for `key` ("chains" / "tiles" / "fused_variants" / "fused_split_tiles"): the plan handed to the constructor
+        while the batch shape it was recorded for is being built (`_plan_on`; the chains of a multi-chain engine inherit it), else
+        the measurement switches HAWQ_CHAINS / HAWQ_TILES / HAWQ_ER_TILES / HAWQ_ER_SPLIT_TILES, else None (tune)."""
+        pl = getattr(self, "plan", None)
+        if pl and getattr(self, "_plan_on", False) and pl.get(key) not in (None, ""):
+            return str(pl[key])
+        return os.environ.get({"chains": "HAWQ_CHAINS", "tiles": "HAWQ_TILES", "fused_variants": "HAWQ_ER_TILES",
+                               "fused_split_tiles": "HAWQ_ER_SPLIT_TILES"}[key])
+
+    def export_plan(self):
+        """The plan of the batch shape built last, as plain strings (what bench.py prints as config.autotuned_tiles / fused_variants /
+        fused_split_tiles / concurrent_sub_batches): feed it back through ``IntegerEngine(model, plan=...)`` to replay it."""
+        if self._batch is None:
+            raise RuntimeError("export_plan: no batch shape has been built yet")
+        return {"batch": int(self._batch[0]), "chains": int(self.chains),
+                "tiles": ".".join(str(t) for t in self.tile_choice.values()),
+                "fused_variants": ".".join(str(t) for t in self.er_choice.values()),
+                "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(self, "er_split_tiles", {}).values()),
+                "conv_launches": list(self.tile_choice.keys()), "pair_launches": list(self.er_choice.keys()),
+                # guards against replaying a plan on a build whose kernels are numbered differently
+                "num_conv_tiles": int(_lib.load().hawq_conv2d_num_tiles()),
+                "pair_variant_counts": [int(_lib.load().hawq_conv_expand_reduce_variants(C.byref(p.er))) for p in (self.subs[0] if self.subs else self)._er_args]}
 
     def _plan_snapshot(self):
         """Tile / fused-variant choice of every launch of the current plan (one entry per chain)."""
@@ -514,11 +566,12 @@ class IntegerEngine:
             for i in range(self.chains):
                 b1 = b0 + split[i]
                 sub = IntegerEngine(None, _parent=self)
+                sub._plan_on = getattr(self, "_plan_on", False)
                 sub._build(b1 - b0, H, W, self.x_in[b0:b1], self.logits[b0:b1])
                 self.subs.append(sub)
                 b0 = b1
             self._ops, self._keep, self._batch, self._graph = _OpList(), [], (N, H, W), None
-            if (self.autotune and not os.environ.get("HAWQ_TILES") and os.environ.get("HAWQ_JOINT_TUNE", "1") != "0"
+            if (self.autotune and not self._fixed("tiles") and os.environ.get("HAWQ_JOINT_TUNE", "1") != "0"
                     and all(hasattr(sub, "_tile_times") for sub in self.subs)):
                 self._autotune_joint()
             self.n_fast, self.n_conv, self.n_k0, self.n_tie = (self.subs[0].n_fast, self.subs[0].n_conv, self.subs[0].n_k0,
@@ -745,23 +798,34 @@ class IntegerEngine:
         _lib.call("hawq_event_create", C.byref(e0))
         _lib.call("hawq_event_create", C.byref(e1))
         ms = C.c_float()
-        fixed = os.environ.get("HAWQ_TILES")  # dotted list as printed by bench.py: replay a recorded choice, no timing
+        # replay a recorded choice, no timing: the constructor's plan for this batch size, or HAWQ_TILES (dotted list as bench.py prints it).
+        # A chain of a multi-chain engine replays the plan of the WHOLE batch it is a part of
+        fixed = self._fixed("tiles")
         if fixed:
             ids = [int(v) for v in fixed.split(".")]
             if len(ids) != len(self._conv_args):
-                raise ValueError(f"HAWQ_TILES lists {len(ids)} tiles, the plan has {len(self._conv_args)} conv launches")
+                raise StalePlan(f"the recorded plan lists {len(ids)} tiles, this plan has {len(self._conv_args)} conv launches")
+            counts = self.plan.get("pair_variant_counts") if getattr(self, "_plan_on", False) else None
+            if counts is not None and list(counts) != [int(_lib.load().hawq_conv_expand_reduce_variants(C.byref(p.er))) for p in self._er_args]:
+                raise StalePlan("the fused expand(-> reduce) kernels of this build are numbered differently")
             for name, a, tid in zip(self._conv_names, self._conv_args, ids):
                 a.tile = tid
                 self.tile_choice[name] = tid
+            split = self._fixed("fused_split_tiles")
+            split = [int(x) for x in split.split(".")] if split else None
+            self.er_split_tiles = getattr(self, "er_split_tiles", {})
             for k, (name, pair) in enumerate(zip(self._er_names, self._er_args)):
-                v = os.environ.get("HAWQ_ER_TILES", ".".join(["1"] * len(self._er_args))).split(".")[k]
+                v = (self._fixed("fused_variants") or ".".join(["1"] * len(self._er_args))).split(".")[k]
                 pair.er.tile = int(v)
                 pair.fused = pair.er.tile != 0
-                if not pair.fused:
-                    te, tr = (int(x) for x in os.environ["HAWQ_ER_SPLIT_TILES"].split(".")[2 * k:2 * k + 2])
+                if split is not None:   # tiles of the pair's two-launch form (what runs when the recorded variant is 0)
+                    te, tr = split[2 * k:2 * k + 2]
                     pair.expand.tile = te
                     if pair.reduce is not None:
                         pair.reduce.tile = tr
+                    self.er_split_tiles[name] = (te, tr)
+                elif not pair.fused:
+                    raise StalePlan("the recorded plan runs a pair as two launches but lists no tiles for them")
                 self.er_choice[name] = pair.er.tile
             return
         with torch.cuda.stream(self.stream):

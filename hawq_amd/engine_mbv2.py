@@ -126,13 +126,25 @@ def _relu6_is_relu(s_a, s_w, m, e, q_hi) -> bool:
 class MobileNetV2Engine:
     """Callable: fp32 NCHW images on the GPU -> fp32 logits of the frozen Q_MobileNetV2 (see the module docstring)."""
 
-    def __init__(self, model, from_buffers: bool = False, use_graph: bool = True, keep_accumulators: bool = False, chains: int = 0):
-        """``chains``: 1 = one launch chain; 2 = the batch split into two sub-batches whose chains run on two streams inside the
+    def __init__(self, model, from_buffers=None, use_graph: bool = True, keep_accumulators: bool = False, chains: int = 0):
+        """``from_buffers``: run on the modules' integer buffers / stored scales (a network restored by ``load_quantized_checkpoint``)
+        instead of re-deriving them from float weights and ranges; None = whatever the modules themselves are marked as
+        (``use_integer_buffers``, set by the loader) - a mix of loaded and re-derived parameters is refused.
+        ``chains``: 1 = one launch chain; 2 = the batch split into two sub-batches whose chains run on two streams inside the
         one hipGraph (tails, prologues and dispatch gaps of one overlap the other's kernels, as in the ResNet engine); 0 = decided
         by timing both at the first call of a batch shape (HAWQ_MBV2_CHAINS overrides)."""
         if not model.is_frozen():
             raise RuntimeError("MobileNetV2Engine needs a frozen model (freeze_model) - ranges must be fixed")
         _lib.load()
+        marks = {bool(getattr(m, "use_integer_buffers", False)) for m in model.modules() if hasattr(m, "weight_integer")}
+        if from_buffers is None:
+            if len(marks) > 1:
+                raise RuntimeError("MobileNetV2Engine: some modules run on loaded integer buffers and others do not - reload the checkpoint "
+                                   "(load_quantized_checkpoint) or the float weights (load_state_dict) as a whole")
+            from_buffers = bool(marks and marks.pop())
+        elif not from_buffers and True in marks:
+            raise RuntimeError("MobileNetV2Engine(from_buffers=False) on a network restored from an integer checkpoint: its float weights and "
+                               "ranges are placeholders - pass from_buffers=True (or None) or load float weights first")
         self.model, self.from_buffers, self.use_graph, self.keep_acc = model, from_buffers, use_graph and not keep_accumulators, keep_accumulators
         self.dev = next(model.parameters()).device
         if self.dev.type != 'cuda':
@@ -279,6 +291,14 @@ class MobileNetV2Engine:
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
 
     def _time_graph(self, reps: int = 12) -> float:
+        # seeded N(0, 1) images (HAWQ_TUNE_INPUT=zero: an all-zero batch), as IntegerEngine._time_graph does: uninitialised memory made
+        # the 1-vs-2 chain choice depend on whatever the allocator handed out
+        if os.environ.get("HAWQ_TUNE_INPUT", "normal") == "zero":
+            self.x_in.zero_()
+        else:
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(0)
+            self.x_in.normal_(generator=g)
         e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
         _lib.call("hawq_event_create", C.byref(e0))
         _lib.call("hawq_event_create", C.byref(e1))

@@ -114,7 +114,14 @@ class Q_MobileNetV2(nn.Module):
 
     def forward(self, x):
         if self.fused and x.is_cuda and not self.training and self.is_frozen():
-            return self.engine()(x)
+            try:
+                return self.engine()(x)
+            except NotImplementedError as exc:
+                # a configuration the fused plan does not take (other input / unit-output QuantAct widths, a classifier bias, a
+                # ReLU6 that does not fold): the module-by-module path computes it, as it did before the plan existed
+                import warnings
+                warnings.warn(f"Q_MobileNetV2: fused integer plan not applicable ({exc}); using the module-by-module path")
+                self.fused = False
         return self.forward_modules(x)
 
     def forward_modules(self, x):
@@ -152,6 +159,20 @@ class Q_MobileNetV2(nn.Module):
         trust_integer_buffers(self, False)
         if getattr(self, "engine_defaults", None):
             self.engine_defaults = dict(self.engine_defaults, from_buffers=False)
+
+
+def q_get_mobilenetv2(model, width_scale, remove_exp_conv=False):
+    """The reference's generic entry point (q_mobilenetv2.py:212-236: ``q_get_mobilenetv2(model, width_scale, remove_exp_conv)``).
+    Its two extra arguments describe the float network handed in; this builder reads the same facts off the network itself, so they
+    are only checked: a width other than the float model's, or ``remove_exp_conv`` that contradicts its first unit, is an error."""
+    width = {"mobilenetv2_w1": 1.0, "mobilenetv2_w3d4": 0.75, "mobilenetv2_wd2": 0.5, "mobilenetv2_wd4": 0.25}.get(getattr(model, "arch", "mobilenetv2_w1"))
+    if width is not None and abs(float(width_scale) - width) > 1e-9:
+        raise ValueError(f"width_scale={width_scale} but the float network is {getattr(model, 'arch', 'mobilenetv2_w1')}")
+    first = next(iter(next(s for n, s in model.features.named_children() if n.startswith("stage")).children()))
+    has_exp = getattr(first, "use_exp_conv", hasattr(first, "conv1"))
+    if bool(remove_exp_conv) == bool(has_exp):
+        raise ValueError(f"remove_exp_conv={remove_exp_conv} contradicts the float network (first unit {'has' if has_exp else 'has no'} expansion conv)")
+    return Q_MobileNetV2(model)
 
 
 def q_mobilenetv2_w1(model):

@@ -103,10 +103,51 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert d["weak"]["global_batch"] == 16 and d["weak"]["batch_per_gpu"] == 8 and d["weak"]["every_rank_parity"] is True
     assert d["strong"]["global_batch"] == 8 and d["strong"]["batch_per_gpu"] == 4 and d["strong"]["every_rank_parity"] is True
     assert d["value"] == d["weak"]["value"]
+    # rank 0's plan is broadcast and every rank holds it (hawq_amd.dist.share_plan / plans_identical): one plan for the whole job
+    assert d["config"]["plan_identical_on_all_ranks"] is True and d["config"]["plan_is_rank0s"] is True
+    assert d["config"]["plan"]["tiles"] == "3.4.5.6.7" and d["config"]["plan"]["fused_variants"] == "1.0"
     # a launcher that provides another world size than --gpus asks for is refused, not silently accepted
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-spawn"], cwd=root, env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _plan_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from hawq_amd.dist import gather_logits, plans_identical, share_plan
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    own = {"batch": 128, "chains": 2, "tiles": f"{rank}.{rank + 1}", "fused_variants": "7.0"}
+    before = plans_identical(own)
+    shared = share_plan(own if rank == 0 else None)
+    # the ragged gather honours a preallocated output: 7 images over 2 ranks
+    lo, hi = (0, 4) if rank == 0 else (4, 7)
+    full = torch.arange(70, dtype=torch.float32).reshape(7, 10)
+    out = torch.full((7, 10), -1.0)
+    res = gather_logits(full[lo:hi], 7, out=out)
+    try:
+        gather_logits(full[lo:hi], 7, out=torch.empty(8, 10))
+        refused = False
+    except ValueError:
+        refused = True
+    q.put((rank, before, plans_identical(shared), shared, bool(res.data_ptr() == out.data_ptr() and torch.equal(out, full)), refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_share_plan_gives_every_rank_rank0s_plan_and_ragged_gather_honours_out():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, before, after, shared, out_ok, refused in res:
+        assert before is False and after is True and shared["tiles"] == "0.1" and out_ok and refused
 
 
 def _world1_worker(port, q):

@@ -254,6 +254,42 @@ def test_concurrent_sub_batches_are_bit_identical():
         del os.environ["HAWQ_JOINT_TUNE"]
 
 
+def test_recorded_plan_replays_without_tuning_and_a_stale_plan_is_refused():
+    """IntegerEngine.export_plan() -> IntegerEngine(model, plan=...): the second engine builds the recorded batch shape by REPLAY
+    (same tiles / fused variants / chain count, identical logits, no joint timing tables), tunes any other batch shape as usual,
+    and a plan recorded for another kernel inventory or launch list falls back to tuning (what bench.py --plan and the multi-GPU
+    path rely on)."""
+    import json
+    from hawq_amd.api import calibrate
+    from hawq_amd.engine import IntegerEngine
+    from hawq_amd.skeleton import synthetic_images
+    model = H.build_model("resnet50", "uniform8")
+    calibrate(model, _images().cuda())
+    x = (synthetic_images(48, seed=5) * 1.2).cuda()
+    tuned = IntegerEngine(model, chains=2)
+    ref = tuned(x).clone()
+    plan = json.loads(json.dumps(tuned.export_plan()))   # survives a JSON round trip (profiles/plans.json, broadcast_object_list)
+    assert plan["batch"] == 48 and plan["chains"] == 2 and len(plan["tiles"].split(".")) == len(plan["conv_launches"])
+    assert tuned.plan_source == "tuned in this process"
+    rep = IntegerEngine(model, plan=dict(plan, source="replayed unit-test plan"))
+    y = rep(x).clone()
+    assert torch.equal(y, ref) and torch.equal(rep(x), ref)
+    got = rep.export_plan()
+    assert {k: got[k] for k in ("batch", "chains", "tiles", "fused_variants", "fused_split_tiles")} == \
+           {k: plan[k] for k in ("batch", "chains", "tiles", "fused_variants", "fused_split_tiles")}
+    assert rep.plan_source == "replayed unit-test plan"
+    assert not hasattr(rep.subs[0], "_tile_times") or not rep.subs[0]._tile_times   # nothing was timed
+    # another batch shape on the same engine: tuned, not replayed
+    x2 = x[:5]
+    assert torch.equal(rep(x2), IntegerEngine(model, chains=1)(x2))
+    # stale plans: other tile inventory / other launch list -> tuning, same logits
+    for bad in (dict(plan, num_conv_tiles=plan["num_conv_tiles"] + 1), dict(plan, conv_launches=plan["conv_launches"][:-1]),
+                dict(plan, pair_variant_counts=[c + 1 for c in plan["pair_variant_counts"]])):
+        e = IntegerEngine(model, plan=bad, chains=1)
+        assert torch.equal(e(x), ref)
+        assert e.plan_source == "tuned in this process"
+
+
 def test_model_call_uses_fused_engine_and_cpu_raises():
     from hawq_amd.api import calibrate
     model = H.build_model("resnet18", "uniform8")
