@@ -375,7 +375,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_pipelined_kernel
 
 // (C = 256 with 8 producers would need 16 waves at <= 128 registers: the 64 GEMM2 accumulators + 16 of GEMM1 leave too few - 184 spills)
 // scheduling groups (SG): pinning GEMM2's MFMAs after every channel group, after every second one or leaving them to the compiler
-// measured the same (34.8 / 34.8 / 36.4 us at batch 64: the kernel is VALU-bound, profiles/r04_pair_kernels_valu_bound.md); SG = 2 is the
+// measured the same (34.8 / 34.8 / 36.4 us at batch 64: the kernel is VALU-bound, profiles/r04_pair_kernels.md); SG = 2 is the
 // form of C = 256 that allocates without a spill
 using P256B = E2Cfg<256, 4, 4, 3, 2>;   // stage 3: 128 pixels, 8 compute + 4 producer waves, 146 KiB: one workgroup per CU, 162-168 registers
 using P128A = E2Cfg<128, 4, 8, 4>;   // stage 2: 128 pixels, 8 + 8 waves, 98 KiB
