@@ -128,8 +128,10 @@ class MobileNetV2Engine:
 
     def __init__(self, model, from_buffers=None, use_graph: bool = True, keep_accumulators: bool = False, chains: int = 0):
         """``from_buffers``: run on the modules' integer buffers / stored scales (a network restored by ``load_quantized_checkpoint``)
-        instead of re-deriving them from float weights and ranges; None = whatever the modules themselves are marked as
-        (``use_integer_buffers``, set by the loader) - a mix of loaded and re-derived parameters is refused.
+        instead of re-deriving them from float weights and ranges; None (the default) = whatever the modules themselves are marked as
+        (``use_integer_buffers``, set by the loader), and a network whose modules disagree is refused - so that an engine built directly
+        on a model restored by ``load_quantized_checkpoint`` cannot silently re-derive scales from placeholder ranges.  An explicit
+        False keeps the activation scales re-derived from the modules' ranges (tests load reference ranges that way).
         ``chains``: 1 = one launch chain; 2 = the batch split into two sub-batches whose chains run on two streams inside the
         one hipGraph (tails, prologues and dispatch gaps of one overlap the other's kernels, as in the ResNet engine); 0 = decided
         by timing both at the first call of a batch shape (HAWQ_MBV2_CHAINS overrides)."""
@@ -142,9 +144,6 @@ class MobileNetV2Engine:
                 raise RuntimeError("MobileNetV2Engine: some modules run on loaded integer buffers and others do not - reload the checkpoint "
                                    "(load_quantized_checkpoint) or the float weights (load_state_dict) as a whole")
             from_buffers = bool(marks and marks.pop())
-        elif not from_buffers and True in marks:
-            raise RuntimeError("MobileNetV2Engine(from_buffers=False) on a network restored from an integer checkpoint: its float weights and "
-                               "ranges are placeholders - pass from_buffers=True (or None) or load float weights first")
         self.model, self.from_buffers, self.use_graph, self.keep_acc = model, from_buffers, use_graph and not keep_accumulators, keep_accumulators
         self.dev = next(model.parameters()).device
         if self.dev.type != 'cuda':
