@@ -10,7 +10,10 @@ lib.load()
 rng = np.random.default_rng(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 ONLY = int(os.environ.get("ERPROBE_ONLY", 0))   # only the shape with this feature-map size, and only its fused variants (PMC runs)
-for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (7, 512, 2048)):
+SHAPES = ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (7, 512, 2048))
+if os.environ.get("ERPROBE_C3"):   # slope / intercept runs: the stage-3 pair with other numbers of 64-channel slices (C3 = 128 .. 2048)
+    SHAPES = tuple((14, 256, int(v)) for v in os.environ["ERPROBE_C3"].split(","))
+for (h, c, c3) in SHAPES:
     if ONLY and h != ONLY:
         continue
     M = N * h * h
@@ -71,7 +74,7 @@ for (h, c, c3) in ((56, 64, 256), (28, 128, 512), (14, 256, 1024), (7, 512, 2048
     for tile in range(1, lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) + 1):
         a.tile = tile
         lib.call("hawq_conv_expand_reduce", C.byref(a), None)
-        if os.environ.get("HAWQ_DBG"):
+        if os.environ.get("HAWQ_DBG") and not os.environ.get("ERPROBE_TIME"):   # stamp runs print from inside the library
             continue
         e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
