@@ -22,15 +22,8 @@ else
 fi
 P="--plan $O/${tag}_plans.json"
 if [ -z "$LIGHT" ]; then
-  # single chain: the same tiles / variants with one launch chain (per-launch table against the FUSED plan's byte model)
-  python - <<PY
-import json
-d = json.load(open("$O/${tag}_plans.json"))
-for v in d.values():
-    v["chains"] = 1
-json.dump(d, open("$O/${tag}_plans_single_chain.json", "w"))
-PY
-  python bench.py $W --plan $O/${tag}_plans_single_chain.json --no-cpu-baseline --no-extra --per-op $O/${tag}_perop_single_chain.md > $O/${tag}_bench_single_chain.json 2>/dev/null
+  # single chain, TUNED as a single chain (as in rounds 1-3, so the per-launch tables compare across rounds): per-launch table against the FUSED plan's byte model
+  HAWQ_CHAINS=1 python bench.py $W --retune --no-cpu-baseline --no-extra --per-op $O/${tag}_perop_single_chain.md > $O/${tag}_bench_single_chain.json 2>/dev/null
 fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.py $W $P --no-cpu-baseline --no-extra --steps 20 --warmup 5 > $O/${tag}_bench_under_rocprof.json 2>/dev/null
