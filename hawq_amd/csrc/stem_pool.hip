@@ -168,8 +168,19 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
     // pair idle, and the 4 pooled rows of a wave fold onto each other two-way).  The 126 fragment reads per wave were the
     // kernel's largest single cost (4 MB of LDS reads per CU per 8 workgroups).
     __shared__ __attribute__((aligned(16))) char patch[4 * SF_PATCH + 32];
+    // fast contract: per-channel fused requant constants {m, (e - 32) | k << 8, lo32(C), hi32(C)}, C = (bias << k) * m + 2^(e-1) - the form
+    // of hawq_amd.packing.pack_ctab, built here from (bias, m, e) by the first 64 threads while the others already fetch the patch.  The
+    // epilogue then reads ONE 16-byte LDS entry per output instead of three global table words, and a requant is shift + v_mad_i64_i32 +
+    // shift (round 4: the epilogue was 11 of the launch's 54 us at batch 64, tools/stemprobe.py with HAWQ_DBG=64)
+    __shared__ __attribute__((aligned(16))) int ctab_s[64 * 4];
     char *const patch8 = patch + 2 * SF_PATCH + 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (fast && t < 64) {
+        const int mm = m[t], ek = e[t], ee = ek & 0xff, kk = ek >> 8;
+        const long long cc = ((long long)bias[t] << kk) * (long long)mm + (1ll << (ee - 1));
+        const v4i ent = {mm, (ee - 32) | (kk << 8), (int)(unsigned)cc, (int)(cc >> 32)};
+        *reinterpret_cast<v4i *>(ctab_s + 4 * t) = ent;
+    }
     const int l31 = lane & 31, h = lane >> 5;
     const int bw = (Wp + 7) >> 3, bh = (Hp + 7) >> 3;
     int b = blockIdx.x;
@@ -364,20 +375,25 @@ __global__ __launch_bounds__(256, 4) void stem_fused_kernel(
         if (!pvalid || HAWQ_DBG_BIT(dbg, 64)) continue;
         const int ch = c * 32 + h * 16;
         int r16[16], qa[16];
+        if (fast) {  // host-proved tie-free tables (hawq_amd.quant_utils.tables_are_fast): fused constants from LDS, 3-instruction requants
+            const DyNt dq = dynt_prepare(mq, eq);
+            const int lo0 = max(a_lo, 0);   // QuantAct16's clamp and the ReLU behind it in one v_med3 (a_hi >= 0)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const v4i b4 = *reinterpret_cast<const v4i *>(bias + ch + 4 * g), m4 = *reinterpret_cast<const v4i *>(m + ch + 4 * g),
-                      e4 = *reinterpret_cast<const v4i *>(e + ch + 4 * g);
-            const int bb[4] = {b4.x, b4.y, b4.z, b4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
-            if (fast) {  // host-proved tie-free tables (hawq_amd.quant_utils.tables_are_fast): 3-instruction requant
-                const DyNt dq = dynt_prepare(mq, eq);
+            for (int j = 0; j < 16; ++j) {
+                const v4i t4 = *reinterpret_cast<const v4i *>(ctab_s + 4 * (ch + j));
+                DyNt d;
+                d.m = t4.x, d.s = t4.y & 31, d.k = t4.y >> 8;
+                d.add = (long long)(((unsigned long long)(unsigned)t4.w << 32) | (unsigned)t4.z);
+                const int v = med3i(dyadic_nt(best[j], d), lo0, a_hi);
+                r16[j] = v;
+                qa[j] = med3i(dyadic_nt(v, dq), q_lo, q_hi);
+            }
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int v = max(clampi(dyadic_nt(best[4 * g + j] + bb[j], dynt_prepare(mm[j], ee[j])), a_lo, a_hi), 0);
-                    r16[4 * g + j] = v;
-                    qa[4 * g + j] = clampi(dyadic_nt(v, dq), q_lo, q_hi);
-                }
-            } else {
+            for (int g = 0; g < 4; ++g) {
+                const v4i b4 = *reinterpret_cast<const v4i *>(bias + ch + 4 * g), m4 = *reinterpret_cast<const v4i *>(m + ch + 4 * g),
+                          e4 = *reinterpret_cast<const v4i *>(e + ch + 4 * g);
+                const int bb[4] = {b4.x, b4.y, b4.z, b4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int v = max(clampi(dyadic_rne(best[4 * g + j] + bb[j], mm[j], ee[j]), a_lo, a_hi), 0);
@@ -641,7 +657,7 @@ int stem_fused_launch(const float *x, const uint8_t *xu8, const int8_t *lut, int
     HAWQ_REQUIRE(res_out || out_q, "hawq_stem_fused: no output requested");
     HAWQ_REQUIRE(C >= 1 && C <= 3 && N > 0 && H >= 7 && W >= 7, "hawq_stem_fused: bad geometry (C <= 3)");
     HAWQ_REQUIRE(!out_q || out_bits == 8 || out_bits == 4, "hawq_stem_fused: out_bits 4/8");
-    HAWQ_REQUIRE(a_lo >= -32768 && a_hi <= 65535, "hawq_stem_fused: 16-bit activation range expected");
+    HAWQ_REQUIRE(a_lo >= -32768 && a_hi <= 65535 && a_hi >= 0, "hawq_stem_fused: 16-bit activation range expected");
     HAWQ_REQUIRE(!lut || (reinterpret_cast<size_t>(lut) & 3) == 0, "hawq_stem_fused_u8: lut must be 4-byte aligned");
     const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1;    // conv 7x7 / 2, pad 3
     const int Hp = (Hc + 2 - 3) / 2 + 1, Wp = (Wc + 2 - 3) / 2 + 1;  // max-pool 3x3 / 2, pad 1
