@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("flags", vp), ("tile", i32), ("ctab", vp), ("ctab_id", vp), ("fast_tables", i32),
         ("in_planar", i32), ("out_planar", i32),
         ("res_no_relu", i32), ("res_clamp16", i32),
+        ("in_pitch", i32), ("out_pitch", i32),
     ]
 
 
@@ -117,7 +118,7 @@ def load():
         fn.restype = C.c_int
     lib.hawq_last_error.restype = C.c_char_p
     lib.hawq_last_error.argtypes = []
-    if lib.hawq_abi_version() != 3:
+    if lib.hawq_abi_version() != 4:
         raise HawqLibraryError("libhawq_mi355.so ABI version mismatch")
     _lib = lib
     return lib

@@ -254,7 +254,8 @@ bool band_persist_applies(const hawq_conv_args *a) {
     const int wo = a->W, band_rows = (BM + wo - 1) / wo + 1 + 2;
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 &&
            a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 && a->Cin == 64 &&
-           a->Cout == 64 && !a->out_planar && a->ctab && band_rows * (wo + 2) <= ZP &&
+           a->Cout == 64 && !a->out_planar && a->ctab && band_rows * (wo + 2) <= ZP && (a->in_pitch == 0 || a->in_pitch == 64) &&
+           (a->out_pitch == 0 || a->out_pitch == 64) &&
            (long long)a->N * a->H * a->W < (1ll << 23);
 }
 

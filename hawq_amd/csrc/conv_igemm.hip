@@ -50,6 +50,8 @@ struct ConvP {
     int res_no_relu, res_clamp16;   // exact general RESIDUAL epilogue: no ReLU after the sum / clamp to the int16 range (hawq_conv_args)
     int ring_bytes;  // LDS bytes of the operand ring actually allocated (fewer stages when the K loop is shorter than the ring)
     int in_planar, out_planar;  // activation layout of in / out_q: 0 = NHWC rows, 1 = channel-group planes (hawq_mi355.h)
+    int gfast;                  // general (direct) RESIDUAL epilogue with the fast contract's arithmetic: 32-bit / signed residuals whose tables the host has proved
+    int in_pitch, out_pitch;    // bytes per pixel row of `in` / channels per pixel row of out_q, res_out, res_in (hawq_conv_args, ABI 4; always > 0 here)
     int dbg;  // HAWQ_DBG ablation bits (timing experiments only): 1 = skip operand loads, 2 = skip MFMAs
     long long *dbgbuf;  // HAWQ_DBG & 128: per-phase cycle sums of workgroup 0 / wave 0 (band kernel)
 };
@@ -117,7 +119,8 @@ template <class C, int A_BITS, int W_BITS>
 __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const uint8_t *__restrict__ in,
                                              const uint8_t *__restrict__ wgt, int H, int W, int Cin, int KH,
                                              int KW, int stride, int pad, int Ho, int Wo, int M, int Cout,
-                                             int m0, int c0, char *smem) {
+                                             int m0, int c0, char *smem, int apitch) {
+    // apitch: bytes from one pixel row of `in` to the next (Cin * A_BITS / 8 when dense)
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wave_m = wave % C::WM, wave_c = wave / C::WM;
@@ -156,7 +159,7 @@ __device__ __forceinline__ void gemm_segment(v16i (&acc)[C::CT][C::PT], const ui
         for (int i = 0; i < C::AL; ++i) {
             const int iy = iy0[i] + kh, ix = ix0[i] + kw;
             const bool v = mval[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const size_t off = ((size_t)(pix_base[i] + kh * W + kw) * Cin + (cc << 6)) * A_BITS / 8 + lslot * ABYTES;
+            const size_t off = (size_t)(pix_base[i] + kh * W + kw) * apitch + (size_t)(cc << 6) * A_BITS / 8 + lslot * ABYTES;
             ra[i] = load_chunk16<A_BITS>(in + (v ? off : 0), v);
         }
 #pragma unroll
@@ -315,7 +318,7 @@ __device__ __forceinline__ void gemm_pipeline(v16i (&acc)[C::CT][C::PT], v16i (&
             for (int i = 0; i < C::AL; ++i) {
                 const int iy = iy0[i] + kh, ix = ix0[i] + kw;
                 const bool v = mval[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const char *src = v ? (const char *)p.in + (size_t)(pix_base[i] + tap_off) * rowb1 + (cc << 6) + asw[i] : zero;
+                const char *src = v ? (const char *)p.in + (size_t)(pix_base[i] + tap_off) * p.in_pitch + (cc << 6) + asw[i] : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(sa + i * (C::RPP * 64)), 16, 0, 0);
             }
@@ -452,15 +455,15 @@ template <class C, int BITS>
 __device__ __forceinline__ void run_segment(v16i (&acc)[C::CT][C::PT], const uint8_t *in, const uint8_t *wgt,
                                             int a_bits, int w_bits, int H, int W, int Cin, int KH, int KW,
                                             int stride, int pad, int Ho, int Wo, int M, int Cout, int m0, int c0,
-                                            char *smem) {
+                                            char *smem, int apitch) {
     if (BITS == 0x88 || (BITS == 0 && a_bits == 8 && w_bits == 8))
-        gemm_segment<C, 8, 8>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
+        gemm_segment<C, 8, 8>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem, apitch);
     else if (BITS == 0x44 || (BITS == 0 && a_bits == 4 && w_bits == 4))
-        gemm_segment<C, 4, 4>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
+        gemm_segment<C, 4, 4>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem, apitch);
     else if (BITS == 0x84 || (BITS == 0 && a_bits == 8 && w_bits == 4))
-        gemm_segment<C, 8, 4>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
+        gemm_segment<C, 8, 4>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem, apitch);
     else
-        gemm_segment<C, 4, 8>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem);
+        gemm_segment<C, 4, 8>(acc, in, wgt, H, W, Cin, KH, KW, stride, pad, Ho, Wo, M, Cout, m0, c0, smem, apitch);
 }
 
 __device__ __forceinline__ v4i ld4(const int32_t *p) { return *reinterpret_cast<const v4i *>(p); }
@@ -482,10 +485,15 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
         for (int q = 0; q < C::PT; ++q) {
             const int pix = m0 + wave_m * (C::PT * 32) + q * 32 + l31;
             if (pix >= p.M) continue;
-            const size_t elem = (size_t)pix * p.Cout + ch;
+            // RAW / DEQUANT address the dense [M][Cout] / [M][ldo] tensors; REQUANT / RESIDUAL rows are out_pitch channels apart (ABI 4)
+            constexpr bool PITCHED = EPI == HAWQ_EPI_REQUANT || EPI == HAWQ_EPI_RESIDUAL;
+            const int opitch = PITCHED ? p.out_pitch : p.Cout;
+            const size_t elem = (size_t)pix * opitch + ch;
             bool ovf = false;
+            int qw[4] = {0, 0, 0, 0};   // int8 output: the lane's 16 channels leave as ONE 16-byte store after the loop
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (PITCHED && ch + 4 * g >= opitch) continue;   // beyond the stored row: nothing to compute, nothing to write
                 const v4i b4 = ld4(p.bias + ch + 4 * g);
                 const int bb[4] = {b4.x, b4.y, b4.z, b4.w};
                 int v[4], qv[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
@@ -507,8 +515,51 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
                         if (p.res_out_bits == 16) reinterpret_cast<v2i *>((uint16_t *)p.res_out + elem)[g] = v2i{0, 0};
                         else reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[g] = v4i{0, 0, 0, 0};
                     }
-                    if ((EPI == HAWQ_EPI_REQUANT || p.out_q) && p.out_bits == 8) reinterpret_cast<uint32_t *>((char *)p.out_q + elem)[g] = 0u;
                     if ((EPI == HAWQ_EPI_REQUANT || p.out_q) && p.out_bits == 4 && !(g & 1)) reinterpret_cast<uint32_t *>((uint8_t *)p.out_q + (elem >> 1) + (g >> 1) * 4)[0] = 0u;
+                } else if (EPI == HAWQ_EPI_RESIDUAL && !DUAL && p.gfast) {
+                    // Fast-contract arithmetic on the direct epilogue (round 4): 32-bit / signed residual tensors (MobileNetV2's carriers)
+                    // keep this epilogue's per-lane accesses, but every table has been lifted and bounded by the host, so a requant is
+                    // shift + v_mad_i64_i32 + shift against the fused constants of `ctab` (bias folded in) instead of dyadic_rne's
+                    // ~15 instructions; p.k0 == 2 keeps the exact round-half-even correction where a tie could not be excluded.
+                    const bool tie = p.k0 == 2;
+                    const DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const v4i t4 = ld4(p.ctab + (size_t)(ch + 4 * g + j) * 4);
+                        DyNt dm;
+                        dm.m = t4.x, dm.s = t4.y & 31, dm.k = t4.y >> 8;
+                        dm.add = (long long)(((unsigned long long)(unsigned)t4.w << 32) | (unsigned)t4.z);
+                        const int av = acc[c][q][4 * g + j];
+                        int ov = tie ? dyadic_tie(av, dm) : dyadic_nt(av, dm);
+                        if (p.res_in) {
+                            const int r = p.res_in_bits == 16 ? (int)((const uint16_t *)p.res_in)[elem + 4 * g + j]
+                                                              : ((const int32_t *)p.res_in)[elem + 4 * g + j];
+                            ov += tie ? dyadic_tie(r, dids) : dyadic_nt(r, dids);
+                        }
+                        if (!p.res_no_relu) ov = max(ov, 0);
+                        if (p.res_clamp16) ov = clampi(ov, -32768, 32767);
+                        o[j] = ov;
+                        qv[j] = clampi(tie ? dyadic_tie(ov, dq) : dyadic_nt(ov, dq), p.q_lo, p.q_hi);
+                        ovf |= ov > 65535;
+                    }
+                    if (p.res_out) {
+                        if (p.res_out_bits == 16) {
+                            v2i w = {min(o[0], 65535) | (min(o[1], 65535) << 16), min(o[2], 65535) | (min(o[3], 65535) << 16)};
+                            reinterpret_cast<v2i *>((uint16_t *)p.res_out + elem)[g] = w;
+                        } else {
+                            v4i w = {o[0], o[1], o[2], o[3]};
+                            reinterpret_cast<v4i *>((int32_t *)p.res_out + elem)[g] = w;
+                        }
+                    }
+                    if (p.out_q) {
+                        if (p.out_bits == 8) {
+                            qw[g] = (int)pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+                        } else {
+                            uint8_t *dst = (uint8_t *)p.out_q + (elem >> 1) + (g >> 1) * 4;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) dst[j] = (g & 1) ? (uint8_t)((dst[j] & 0x0f) | (qv[j] << 4)) : (uint8_t)(qv[j] & 0x0f);
+                        }
+                    }
                 } else {
                     const v4i m4 = ld4(p.m + ch + 4 * g), e4 = ld4(p.e + ch + 4 * g);
                     const int mm[4] = {m4.x, m4.y, m4.z, m4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w};
@@ -556,7 +607,7 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
                     }
                     if (EPI == HAWQ_EPI_REQUANT || p.out_q) {
                         if (p.out_bits == 8) {
-                            reinterpret_cast<uint32_t *>((char *)p.out_q + elem)[g] = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+                            qw[g] = (int)pack4_i8(qv[0], qv[1], qv[2], qv[3]);
                         } else {  // hawq4: byte k of an 8-channel group = c_k | c_{k+4} << 4
                             uint8_t *dst = (uint8_t *)p.out_q + (elem >> 1) + (g >> 1) * 4;
                             if (g & 1) {
@@ -569,6 +620,11 @@ __device__ __forceinline__ void epilogue_generic(const ConvP &p, v16i (&acc)[C::
                         }
                     }
                 }
+            }
+            if constexpr (PITCHED) {
+                // (rows are multiples of 16 channels and ch is one: the lane's 16 bytes are either entirely inside the row or not at all)
+                if ((EPI == HAWQ_EPI_REQUANT || p.out_q) && p.out_bits == 8 && ch < opitch)
+                    *reinterpret_cast<v4i *>((char *)p.out_q + elem) = v4i{qw[0], qw[1], qw[2], qw[3]};
             }
             if (EPI == HAWQ_EPI_RESIDUAL && ovf && p.res_out && p.res_out_bits == 16) atomicOr(p.flags, 1);
         }
@@ -795,8 +851,9 @@ __device__ __forceinline__ void epilogue_fast(const ConvP &p, v16i (&acc)[C::CT]
         for (int i = 0; i < (C::BM * S::QCPR + C::NT - 1) / C::NT; ++i) {
             const int idx = t + C::NT * i;
             const int row = idx / S::QCPR, j = idx % S::QCPR;
-            if (idx < C::BM * S::QCPR && m0 + row < p.M) {
-                const size_t e0 = (size_t)(m0 + row) * p.Cout + c0 + ((j ^ S::qsw(row)) << 4);
+            const int cofs = c0 + ((j ^ S::qsw(row)) << 4);   // first channel of this 16-channel piece
+            if (idx < C::BM * S::QCPR && m0 + row < p.M && cofs < p.out_pitch) {   // (out_pitch < Cout: the row ends before the tile does, ABI 4)
+                const size_t e0 = (size_t)(m0 + row) * p.out_pitch + cofs;
                 if (p.out_bits == 8)
                     *reinterpret_cast<v4i *>((char *)p.out_q + e0) = *reinterpret_cast<const v4i *>(q_tile + idx * 16);
                 else
@@ -870,10 +927,10 @@ __global__ __launch_bounds__(C::NT, C::MINB) void conv_kernel(const ConvP p) {
         if constexpr (ASYNC4) gemm_pipeline<C, DUAL, true>(acc, acc2, p, m0, c0, smem);
     } else {
         run_segment<C, BITS>(acc, p.in, p.wgt, p.in_bits, p.w_bits, p.H, p.W, p.Cin, p.KH, p.KW, p.stride, p.pad,
-                             p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
+                             p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem, p.in_pitch);
         if constexpr (DUAL)
             run_segment<C, BITS2>(acc2, p.in2, p.wgt2, p.in2_bits, p.w2_bits, p.H2, p.W2, p.Cin2, 1, 1, p.stride2,
-                                  0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem);
+                                  0, p.Ho, p.Wo, p.M, p.Cout, m0, c0, smem, p.Cin2 * p.in2_bits / 8);
     }
     if (HAWQ_DBG_BIT(p.dbg, 4)) return;
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -1288,7 +1345,8 @@ bool band_applies(const BandInfo &bi, const hawq_conv_args *a) {
     const bool res = a->epilogue == HAWQ_EPI_RESIDUAL;
     const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q) ||
                         (res && a->res_in && a->res_in_bits == 16 && (!a->res_out || a->res_out_bits == 16));
-    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && epi_ok &&
+    const bool dense = (a->in_pitch == 0 || a->in_pitch == a->Cin * a->in_bits / 8) && (a->out_pitch == 0 || a->out_pitch == a->Cout);
+    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && epi_ok && dense &&
            ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) && a->Cout % bi.bn == 0 &&
            band_rows * (wo + 2) <= bi.band_px - 4 && (bi.bstages > 1 || (a->Cin >> (nib ? 7 : 6)) == 1);
 }
@@ -1442,6 +1500,24 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     p.res_out = a->res_out, p.res_out_bits = a->res_out_bits;
     p.out_q = a->out_q, p.out_bits = a->out_bits, p.q_lo = a->q_lo, p.q_hi = a->q_hi, p.mq = a->mq, p.eq = a->eq;
     p.out_acc = a->out_acc, p.out_f32 = a->out_f32, p.fscale = a->fscale, p.ldo = a->ldo, p.n_valid = a->n_valid;
+    {   // ABI 4: pitches of narrow tensors (0 = dense)
+        const int dense_in = a->Cin * a->in_bits / 8;
+        p.in_pitch = a->in_pitch ? a->in_pitch : dense_in, p.out_pitch = a->out_pitch ? a->out_pitch : a->Cout;
+        if (p.in_pitch != dense_in)
+            HAWQ_REQUIRE(a->in_pitch > 0 && a->in_pitch % 16 == 0 && a->in_pitch < dense_in && a->in_bits == 8 && !a->in_planar,
+                         "hawq_conv2d: in_pitch=%d needs a multiple of 16 below the dense row (%d bytes), int8 activations, NHWC rows", a->in_pitch, dense_in);
+        if (p.out_pitch != a->Cout) {
+            const bool fast_ = a->fast_tables != 0;
+            HAWQ_REQUIRE(a->out_pitch > 0 && a->out_pitch % 16 == 0 && a->out_pitch < a->Cout, "hawq_conv2d: out_pitch=%d needs a multiple of 16 below Cout=%d", a->out_pitch, a->Cout);
+            HAWQ_REQUIRE((a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL) && !a->in2 && !a->out_planar && (!a->out_q || a->out_bits == 8),
+                         "hawq_conv2d: out_pitch exists for single-branch REQUANT / RESIDUAL launches with int8 NHWC outputs");
+            const bool direct_ = a->epilogue == HAWQ_EPI_RESIDUAL &&   // the direct epilogue addresses pitched rows (ConvP.gfast), the fast RESIDUAL tiles are dense
+                                 (a->res_no_relu || a->res_clamp16 || !a->res_in || a->res_in_bits == 32 || (a->res_out && a->res_out_bits == 32));
+            HAWQ_REQUIRE(!fast_ || a->epilogue == HAWQ_EPI_REQUANT || direct_,
+                         "hawq_conv2d: out_pitch with fast_tables needs the REQUANT epilogue or a signed / 32-bit RESIDUAL (the unsigned 16-bit fast RESIDUAL tiles are dense)");
+            HAWQ_REQUIRE(a->n_valid <= a->out_pitch, "hawq_conv2d: n_valid=%d exceeds out_pitch=%d", a->n_valid, a->out_pitch);
+        }
+    }
     p.flags = a->flags;
     p.ctab = a->ctab, p.ctab_id = a->ctab_id;
     static const int dbg_env = HAWQ_DBG_ENV();
@@ -1456,7 +1532,9 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     if (fast && (a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL)) {
         HAWQ_REQUIRE(a->ctab && (!dual || a->ctab_id), "hawq_conv2d: fast_tables needs ctab (and ctab_id)");
         if (a->epilogue == HAWQ_EPI_REQUANT && a->relu && p.q_lo < 0) p.q_lo = 0;  // ReLU folded into the clamp
-        HAWQ_REQUIRE(a->epilogue != HAWQ_EPI_RESIDUAL || !a->out_q || a->q_lo <= 0,
+        const bool direct_form = a->epilogue == HAWQ_EPI_RESIDUAL && !dual &&   // runs the direct epilogue (clamps q on both sides), see ConvP.gfast
+                                 (a->res_no_relu || a->res_clamp16 || !a->res_in || a->res_in_bits == 32 || (a->res_out && a->res_out_bits == 32));
+        HAWQ_REQUIRE(a->epilogue != HAWQ_EPI_RESIDUAL || !a->out_q || a->q_lo <= 0 || direct_form,
                      "hawq_conv2d: fast RESIDUAL needs q_lo <= 0");
     }
     auto e_fast = [](int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62; };
@@ -1494,9 +1572,10 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             break;
         case HAWQ_EPI_RESIDUAL:
             HAWQ_REQUIRE(a->m && a->e, "hawq_conv2d: RESIDUAL needs m, e");
-            HAWQ_REQUIRE(dual || a->res_in || !fast, "hawq_conv2d: the fast RESIDUAL epilogue needs res_in or a second branch");
             HAWQ_REQUIRE(dual || !a->res_in || a->res_in_bits == 16 || a->res_in_bits == 32, "hawq_conv2d: res_in_bits 16/32");
-            HAWQ_REQUIRE(!fast || (!a->res_no_relu && !a->res_clamp16), "hawq_conv2d: res_no_relu / res_clamp16 exist on the exact general path only (fast_tables == 0)");
+            HAWQ_REQUIRE(!(dual && (a->res_no_relu || a->res_clamp16)), "hawq_conv2d: res_no_relu / res_clamp16 exist for single-branch launches");
+            HAWQ_REQUIRE(!fast || !(a->res_no_relu || a->res_clamp16 || (!dual && !a->res_in)) || (a->fast_tables & 2) == 0,
+                         "hawq_conv2d: fast_tables bit 1 is not defined for the signed / identity-free RESIDUAL forms");
             HAWQ_REQUIRE(!a->res_no_relu || !a->res_out || a->res_out_bits == 32, "hawq_conv2d: a residual stored without ReLU is signed: res_out_bits must be 32");
             HAWQ_REQUIRE(!a->res_out || a->res_out_bits == 32 || (a->res_out_bits == 16 && a->flags),
                          "hawq_conv2d: res_out_bits 16 (with flags) or 32");
@@ -1567,7 +1646,8 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
             const int ks = kTiles[tile].ksub;
             const bool nib_ok = all44 && (a->Cin & 127) == 0 && (!dual || (a->Cin2 & 127) == 0) &&
                                 ((a->KH * a->KW * (a->Cin >> 7)) % ks) == 0 && (!dual || ((a->Cin2 >> 7) % ks) == 0);
-            const bool wide_res_ = a->epilogue == HAWQ_EPI_RESIDUAL && ((!dual && a->res_in_bits == 32) || (a->res_out && a->res_out_bits == 32));
+            const bool wide_res_ = a->epilogue == HAWQ_EPI_RESIDUAL && ((!dual && a->res_in_bits == 32) || (a->res_out && a->res_out_bits == 32) ||
+                                                                        (!dual && (a->res_no_relu || a->res_clamp16 || !a->res_in)));
             const bool tables = a->epilogue == HAWQ_EPI_REQUANT || a->epilogue == HAWQ_EPI_RESIDUAL;
             if (!(all88 || nib_ok) || wide_res_ || (tables && !fast)) tile = kTiles[tile].twin;
         }
@@ -1578,8 +1658,12 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
     const bool wide_res = a->epilogue == HAWQ_EPI_RESIDUAL &&
                           ((!dual && a->res_in_bits == 32) || (a->res_out && a->res_out_bits == 32));
     const bool needs_tables = slot == 1 || slot == 2;
+    // the signed / identity-free RESIDUAL forms (MobileNetV2, ABI 3) live on the direct epilogue like the 32-bit residual tensors do;
+    // with fast_tables they run it with the fast contract's arithmetic (ConvP.gfast)
+    const bool signed_res = a->epilogue == HAWQ_EPI_RESIDUAL && !dual && (a->res_no_relu || a->res_clamp16 || !a->res_in);
+    p.gfast = fast && a->epilogue == HAWQ_EPI_RESIDUAL && !dual && (wide_res || signed_res);
     auto variant = [&](int ab, int wb) {
-        if (wide_res || (needs_tables && !fast)) return 0;
+        if (wide_res || signed_res || (needs_tables && !fast)) return 0;
         return ab == 8 && wb == 8 ? 1 : (ab == 4 && wb == 4 ? 2 : 0);
     };
     KernelFn fn;
@@ -1591,7 +1675,7 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         const bool all88 = a->in_bits == 8 && a->w_bits == 8 && (!dual || (a->in2_bits == 8 && a->w2_bits == 8));
         const int stage_bytes = ti.lds / ti.ns;
         static const bool full_ring = getenv("HAWQ_FULL_RING") != nullptr;  // A/B switch for measurements
-        if (!full_ring && all88 && fast && needs_tables && !wide_res && stages >= 1 && stages < ti.ns &&
+        if (!full_ring && all88 && fast && needs_tables && !wide_res && !signed_res && stages >= 1 && stages < ti.ns &&
             stages * stage_bytes >= ti.BM * ti.BN * (ti.kg > 1 ? 4 : 1))  // (the int8 output tile - split-K: the partial sums - is staged on top of the ring)
             lds = stages * stage_bytes;
     }

@@ -452,7 +452,7 @@ struct ERInfo { ERFn fn[5]; int c, bm, nt, lds; bool dual; };   // fn: {general,
 const ERInfo kER[NUM_ER] = {ER_ENTRY(E64), ER_ENTRY(E64R), ER_ENTRY(E128), ER_ENTRY(E128D), ER_ENTRY(E128P), ER_ENTRY(E256), ER_ENTRY(E256P), ER_ENTRY(E256S), ER_ENTRY(E256SP), ER_ENTRY(E64D)};
 
 bool conv_is_1x1_int8_fast(const hawq_conv_args &a, bool dual_ok = false) {
-    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 &&
+    return (a.in_pitch == 0 || a.in_pitch == a.Cin) && (a.out_pitch == 0 || a.out_pitch == a.Cout) && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 &&
            (dual_ok || !a.in2) && !a.in_planar;
 }
 

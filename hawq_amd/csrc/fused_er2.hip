@@ -390,7 +390,7 @@ struct E2Info { E2Fn fn[5]; int c, bm, nt, lds; };   // fn: {general, exact-tie,
 const E2Info kE2[NUM_E2] = {E2_ENTRY(P256B), E2_ENTRY(P128A), E2_ENTRY(P128B), E2_ENTRY(P64A)};
 
 bool e2_conv_ok(const hawq_conv_args &a) {
-    return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 && !a.in2 && !a.in_planar;
+    return (a.in_pitch == 0 || a.in_pitch == a.Cin) && (a.out_pitch == 0 || a.out_pitch == a.Cout) && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.in_bits == 8 && a.w_bits == 8 && a.fast_tables != 0 && !a.in2 && !a.in_planar;
 }
 
 // index into kE2 of the nth (1-based) variant that takes this pair, or -1

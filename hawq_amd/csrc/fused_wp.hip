@@ -388,7 +388,7 @@ const WPInfo kWP[] = {WP_ENTRY(W64, 1), WP_ENTRY(W64B, 1), WP_ENTRY(W128, 1), WP
 constexpr int NUM_WP = sizeof(kWP) / sizeof(kWP[0]);
 
 bool wp_expand_ok(const hawq_conv_args &e) {
-    return e.KH == 1 && e.KW == 1 && e.stride == 1 && e.pad == 0 && e.in_bits == 8 && e.w_bits == 8 && e.fast_tables != 0 && !e.in2 &&
+    return (e.in_pitch == 0 || e.in_pitch == e.Cin) && (e.out_pitch == 0 || e.out_pitch == e.Cout) && e.KH == 1 && e.KW == 1 && e.stride == 1 && e.pad == 0 && e.in_bits == 8 && e.w_bits == 8 && e.fast_tables != 0 && !e.in2 &&
            !e.in_planar && e.epilogue == HAWQ_EPI_RESIDUAL && e.res_in && e.res_in_bits == 16 && (!e.res_out || e.res_out_bits == 16) &&
            e.flags && e.ctab && e.Cout % 64 == 0 && e.out_bits == 8;
 }

@@ -49,6 +49,15 @@ def _pad64(c: int) -> int:
     return (c + 63) // 64 * 64
 
 
+def _pitch(c: int) -> int:
+    """Channels per STORED pixel row of a c-channel tensor (round 4): the next multiple of 16, not of 64 - MobileNetV2's 16 / 24 / 32 /
+    96 / 144 / 160-channel tensors are stored (almost) at their own width.  The GEMMs still see K and N padded to the 64-channel tile:
+    a conv reads its K = pad64(c) bytes per pixel through `hawq_conv_args.in_pitch` (the bytes beyond the row meet zero weights) and
+    writes only the first `out_pitch` channels of its 64-channel tiles (include/hawq_mi355.h, ABI 4).  HAWQ_MBV2_PAD64=1 restores the
+    64-padded tensors of round 3 (A/B switch for measurements)."""
+    return _pad64(c) if os.environ.get("HAWQ_MBV2_PAD64") else (c + 15) // 16 * 16
+
+
 def _rng(act: QuantAct):
     b = act.activation_bit
     return (-(2 ** (b - 1)), 2 ** (b - 1) - 1) if act.quant_mode == 'symmetric' else (0, 2 ** b - 1)
@@ -62,6 +71,26 @@ def _padded(v, n, fill=0):
     out = np.full(n, fill, np.int64)
     out[:len(v)] = v
     return out
+
+
+def _requant_bound(vmax, m, ek):
+    """Upper bound on |RNE(v * m / 2^e)| for |v| <= vmax (per-channel arrays or scalars; unlifted or lifted tables alike)."""
+    m = np.asarray(m, np.int64).reshape(-1)
+    ek = np.asarray(ek, np.int64).reshape(-1)
+    vmax = np.broadcast_to(np.asarray(vmax, dtype=object), m.shape)
+    return max(((int(v) << int(k)) * int(mm) >> int(e)) + 1 for v, mm, e, k in zip(vmax, m, ek & 0xff, ek >> 8))
+
+
+def _fast_scalar(s_in, s_out, vmax):
+    """Scalar requant table lifted to the fast contract for inputs |v| <= vmax: (m, ek, tie) or None when it does not fit."""
+    try:
+        m, ek = requant_table(s_in, torch.ones(1), s_out, vbits=int(vmax).bit_length())
+    except ValueError:
+        return None
+    vb = int(vmax).bit_length()
+    if not tables_fit_fast(m, ek, vb):
+        return None
+    return int(m[0]), int(ek[0]), not tables_are_fast(m, ek, vb)
 
 
 class _Layer:
@@ -79,6 +108,8 @@ class _Layer:
         self.cout, cg, self.kh, self.kw = w.shape
         self.cin = cg * self.groups
         self.cin_p, self.cout_p = _pad64(self.cin), _pad64(self.cout)
+        # stored width of the input / output tensor (the im2col rows of the init conv are 64 bytes by construction)
+        self.cin_s, self.cout_s = (self.cin_p if im2col else _pitch(self.cin)), _pitch(self.cout)   # (im2col: the init layer, either input form)
         self.s_w = mod.convbn_scaling_factor.detach().float().cpu().reshape(-1)
         b = np.clip(np.rint(mod.bias_integer.detach().cpu().numpy().astype(np.float64)), -2 ** 31, 2 ** 31 - 1).astype(np.int64)
         self.bias = _i32(_padded(b, self.cout_p), dev)
@@ -93,11 +124,24 @@ class _Layer:
         if self.groups == 1:
             self.w = torch.from_numpy(packing.pack_conv_weight(w, 8, self.cin_p, self.cout_p)).to(dev)
         elif self.groups == self.cin == self.cout and (self.kh, self.kw, self.pad) == (3, 3, 1):
-            w9c = np.zeros((9, self.cout_p), np.int8)
+            w9c = np.zeros((9, self.cout_s), np.int8)   # tap-major [3][3][C] with C = the stored width of the tensors it runs on
             w9c[:, :self.cout] = w.reshape(self.cout, 9).T
             self.w = torch.from_numpy(w9c).to(dev)
         else:
             raise NotImplementedError("grouped convolutions other than depthwise 3x3 are outside MobileNetV2")
+
+    def fast_closing(self, s_a, s_out, dev):
+        """Fused constants (packing.pack_ctab, bias folded) of this conv's unit-closing requant when the lifted table fits the fast
+        contract: dict(ctab, tie) or None.  Lets the direct RESIDUAL epilogue run 3-instruction requants (hawq_conv2d, ConvP.gfast)."""
+        try:
+            mm, ee = requant_table(s_a, self.s_w, s_out, vbits=self.vbits)
+        except ValueError:
+            return None
+        if not tables_fit_fast(mm, ee, self.vbits):
+            return None
+        cp = self.cout_p
+        return dict(ctab=_i32(packing.pack_ctab(_padded(self.b_host, cp), _padded(mm, cp), _padded(ee, cp, 33)), dev),
+                    tie=not tables_are_fast(mm, ee, self.vbits))
 
     def table(self, s_a, s_out, dev):
         """(m, e) of QuantAct(conv output): ratio S_a * S_w[c] / S_out, padded channels m = 0"""
@@ -209,15 +253,17 @@ class MobileNetV2Engine:
         md, ed, mh, eh = init.table(s_in, s16, dev)
         if not _relu6_is_relu(float(s_in.item()), init.s_w.numpy(), mh, eh, 32767):
             raise NotImplementedError("quant_act_int32 range above 6.0 behind ReLU6")
-        P['init'] = dict(layer=init, m=md, e=ed)
+        P['init'] = dict(layer=init, m=md, e=ed, fast=init.fast_closing(s_in, s16, dev))
         units = []
         s_prev = s16
+        ob_prev = 32768   # bound on |16-bit output| of the producer in front of the current unit (init: ReLU + clamp)
         for u in m.units():
             d = dict(residual=bool(u.residual))
             qa = u.quant_act
             s_a = self._scale(qa)
             mq, eq = requant_table(s_prev, one, s_a, lift=False)
             d['mq'], d['eq'], d['q_rng'] = int(mq[0]), int(eq[0]), _rng(qa)
+            d['q_fast'] = _fast_scalar(s_prev, s_a, ob_prev)   # the same table lifted for the producer's fast arithmetic
             s_x = s_a
             d['layers'] = []
             for conv, act in u.activated:
@@ -229,23 +275,29 @@ class MobileNetV2Engine:
             proj = _Layer(u.conv3, s_x, dev, self.from_buffers)
             s_o = act16(u.quant_act_int32)
             md, ed, _, _ = proj.table(s_x, s_o, dev)
-            d['proj'] = dict(layer=proj, m=md, e=ed)
+            d['proj'] = dict(layer=proj, m=md, e=ed, fast=proj.fast_closing(s_x, s_o, dev))
+            _, _, mh3, eh3 = proj.table(s_x, s_o, dev)
+            ob = min(_requant_bound([(1 << int(v)) for v in proj.vbits], mh3, eh3), 1 << 30)
             if d['residual']:
                 m1, e1 = requant_table(s_prev, one, s_o, lift=False)
                 d['m_id'], d['e_id'] = int(m1[0]), int(e1[0])
+                d['id_fast'] = _fast_scalar(s_prev, s_o, ob_prev)
+                ob = ob + _requant_bound(ob_prev, m1, e1)   # case 1: the un-clamped sum of the two branches
+            else:
+                ob = min(ob, 32768)                          # case 0 clamps to the 16-bit range
             units.append(d)
-            s_prev = s_o
+            s_prev, ob_prev = s_o, ob
         P['units'] = units
         qb = m.quant_act_before_final_block
         s_b = self._scale(qb)
         mq, eq = requant_table(s_prev, one, s_b, lift=False)
-        P['before_final'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_rng(qb))
+        P['before_final'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_rng(qb), q_fast=_fast_scalar(s_prev, s_b, ob_prev))
         fin = _Layer(m.features.final_block, s_b, dev, self.from_buffers)
         s_f = act16(m.quant_act_int32_final)
         md, ed, mh, eh = fin.table(s_b, s_f, dev)
         if not _relu6_is_relu(float(s_b.item()), fin.s_w.numpy(), mh, eh, 32767):
             raise NotImplementedError("quant_act_int32_final range above 6.0 behind ReLU6")
-        P['final'] = dict(layer=fin, m=md, e=ed)
+        P['final'] = dict(layer=fin, m=md, e=ed, fast=fin.fast_closing(s_b, s_f, dev))
         ao = m.quant_act_output
         s8 = self._scale(ao)
         mq, eq = requant_table(s_f, one, s8, lift=False)
@@ -276,6 +328,8 @@ class MobileNetV2Engine:
         a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = N, H, W, L.cin_p, L.cout_p, L.kh, L.kw, L.stride, L.pad
         a.in_bits = a.w_bits = 8
         a.flags = self.flags.data_ptr()
+        a.in_pitch = L.cin_s if L.cin_s != L.cin_p else 0       # 0 = dense rows
+        a.out_pitch = L.cout_s if L.cout_s != L.cout_p else 0   # (RAW taps reset it: the accumulators are dense [M][Cout])
         return a
 
     def _tap(self, ops, keep, name, a, N, ho, wo, cout, cout_p):
@@ -284,7 +338,7 @@ class MobileNetV2Engine:
         r = _lib.ConvArgs()
         C.memmove(C.byref(r), C.byref(a), C.sizeof(r))
         r.epilogue, r.out_acc, r.res_in, r.res_out, r.out_q = _lib.EPI_RAW, acc.data_ptr(), None, None, None
-        r.fast_tables, r.ctab = 0, None
+        r.fast_tables, r.ctab, r.out_pitch = 0, None, 0
         keep += [acc, r]
         self.taps[name] = (acc, (N, ho, wo, cout_p), cout)
         ops.append(partial(_lib.call, "hawq_conv2d", C.byref(r), self.stream.cuda_stream))
@@ -355,8 +409,10 @@ class MobileNetV2Engine:
         ops, keep, self.taps, self._graph = [], [], {}, None
         self._convs, self._tuned = [], False   # hawq_conv2d argument structs of the plan (tile autotuning)
         self.n_fast = 0
+        self.n_fast_closing = 0   # unit-closing launches whose tables are all proved: the direct epilogue with 3-instruction requants
         self.plan_bytes = N * 3 * H * W * 4   # bytes the plan has to move at the networks' true widths (no padding channels)
-        alloc = lambda n, dt: torch.empty(n, dtype=dt, device=dev)
+        # 64 elements of slack: a conv that reads a narrow tensor through in_pitch fetches up to 48 bytes past the last pixel row
+        alloc = lambda n, dt: torch.empty(n + 64, dtype=dt, device=dev)[:n]
         self.x_in = x_view if x_view is not None else alloc(N * 3 * H * W, torch.float32).view(N, 3, H, W)
         init = P['init']['layer']
         if init.im2col:
@@ -376,7 +432,7 @@ class MobileNetV2Engine:
             ops.append(partial(_lib.call, "hawq_f32_nchw_to_q_nhwc", xq_f.data_ptr(), xq.data_ptr(), N, 3, H, W, init.cin_p, 8, P['s_in'], sp))
             keep += [xq_f, xq]
 
-        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True):
+        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True, fast=None, id_fast=None, q_fast=None):
             """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo);
             the 32-bit carrier is only written where something reads it (the next unit's identity, the pool, a tap)"""
             ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
@@ -384,39 +440,51 @@ class MobileNetV2Engine:
             a.epilogue, a.m, a.e = _lib.EPI_RESIDUAL, m.data_ptr(), e.data_ptr()
             out16 = None
             if need16 or self.keep_acc:
-                out16 = alloc(n * ho * wo * L.cout_p, torch.int32)
+                out16 = alloc(n * ho * wo * L.cout_s, torch.int32)
                 a.res_out, a.res_out_bits = out16.data_ptr(), 32
             self.plan_bytes += n * (h * w * L.cin + ho * wo * L.cout * ((4 if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
+            use_fast = (fast is not None and (res_in is None or id_fast is not None) and (nxt_q is None or q_fast is not None)
+                        and not os.environ.get("HAWQ_MBV2_EXACT"))
             if res_in is not None:
                 a.res_in, a.res_in_bits, a.m_id_scalar, a.e_id_scalar = res_in.data_ptr(), 32, m_id, e_id
+                if use_fast:
+                    a.m_id_scalar, a.e_id_scalar = id_fast[0], id_fast[1]
             a.res_no_relu, a.res_clamp16 = int(not relu), int(clamp16)
             a.n_valid = L.cout   # the exact epilogue skips the padding channels
+            # every table of this launch lifted and bounded by the host -> the direct epilogue's 3-instruction requants (hawq_conv2d,
+            # ConvP.gfast); otherwise its exact dyadic_rne form.  HAWQ_MBV2_EXACT=1: A/B switch for measurements
+            if use_fast:
+                tie = fast['tie'] or (res_in is not None and id_fast[2]) or (nxt_q is not None and q_fast[2])
+                a.fast_tables, a.ctab = (5 if tie else 1), fast['ctab'].data_ptr()
+                self.n_fast_closing = getattr(self, "n_fast_closing", 0) + 1
             q = None
             if nxt_q is not None:
-                q = alloc(n * ho * wo * L.cout_p, torch.int8)
+                q = alloc(n * ho * wo * L.cout_s, torch.int8)
                 a.out_q, a.out_bits, a.mq, a.eq, (a.q_lo, a.q_hi) = q.data_ptr(), 8, nxt_q[0], nxt_q[1], nxt_q[2]
+                if use_fast:
+                    a.mq, a.eq = q_fast[0], q_fast[1]
             if self.keep_acc:
                 self._tap(ops, keep, name, a, n, ho, wo, L.cout, L.cout_p)
             keep.extend([a, out16, q])
             self._convs.append((name, a))
             ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
             if out16 is not None:
-                self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_p), L.cout)
+                self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_s), L.cout)
             if q is not None:
-                self.taps[name + ":next_q"] = (q, (n, ho, wo, L.cout_p), L.cout)
+                self.taps[name + ":next_q"] = (q, (n, ho, wo, L.cout_s), L.cout)
             return out16, q, ho, wo
 
         units = P['units']
         u0 = units[0]
         x16, q, h, w = closing(init, P['init']['m'], P['init']['e'], xq, N, H0, W0, None, 0, 33, True, True,
-                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block", need16=u0['residual'])
+                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block", need16=u0['residual'], fast=P['init']['fast'], q_fast=u0['q_fast'])
         for ui, u in enumerate(units):
             name = f"unit{ui + 1}"
             x = q
             for li, ent in enumerate(u['layers']):
                 L = ent['layer']
                 ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
-                out = alloc(N * ho * wo * L.cout_p, torch.int8)
+                out = alloc(N * ho * wo * L.cout_s, torch.int8)
                 lname = f"{name}.{'conv1' if L.groups == 1 else 'conv2'}"
                 if L.groups == 1:
                     a = self._conv_args(L, x, N, h, w)
@@ -433,25 +501,29 @@ class MobileNetV2Engine:
                     self._convs.append((lname, a))
                     ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
                 else:
-                    acc = alloc(N * ho * wo * L.cout_p, torch.int32) if self.keep_acc else None
+                    acc = alloc(N * ho * wo * L.cout_s, torch.int32) if self.keep_acc else None
                     if acc is not None:
-                        self.taps[lname] = (acc, (N, ho, wo, L.cout_p), L.cout)
+                        self.taps[lname] = (acc, (N, ho, wo, L.cout_s), L.cout)
                     ops.append(partial(_lib.call, "hawq_depthwise3x3_requant", x.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), ent['m'].data_ptr(),
-                                       ent['e'].data_ptr(), N, h, w, L.cout_p, L.cout, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
+                                       ent['e'].data_ptr(), N, h, w, L.cout_s, L.cout, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
                                        None if acc is None else acc.data_ptr(), sp))
                     keep.append(acc)
                 self.plan_bytes += N * (h * w * L.cin + ho * wo * L.cout) + L.weight_bytes
-                self.taps[lname + ":q"] = (out, (N, ho, wo, L.cout_p), L.cout)
+                self.taps[lname + ":q"] = (out, (N, ho, wo, L.cout_s), L.cout)
                 keep.append(out)
                 x, h, w = out, ho, wo
             nxt = units[ui + 1] if ui + 1 < len(units) else None
             nq = (nxt['mq'], nxt['eq'], nxt['q_rng']) if nxt is not None else (P['before_final']['mq'], P['before_final']['eq'], P['before_final']['rng'])
+            nq_fast = nxt['q_fast'] if nxt is not None else P['before_final']['q_fast']
             pr = u['proj']
             x16, q, h, w = closing(pr['layer'], pr['m'], pr['e'], x, N, h, w, x16 if u['residual'] else None, u.get('m_id', 0), u.get('e_id', 33),
-                                   False, not u['residual'], nq, name + ".conv3", need16=bool(nxt is not None and nxt['residual']))
+                                   False, not u['residual'], nq, name + ".conv3", need16=bool(nxt is not None and nxt['residual']),
+                                   fast=pr['fast'], id_fast=u.get('id_fast'), q_fast=nq_fast)
         fin = P['final']
-        x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block")
-        cl = fin['layer'].cout_p
+        x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block", fast=fin['fast'])
+        cl = fin['layer'].cout_s
+        if cl != fin['layer'].cout_p:
+            raise NotImplementedError("the final block's width must be a multiple of 64 (the pool and the classifier read dense rows)")
         qf = alloc(N * cl, torch.int8)
         pooled = alloc(N * cl, torch.int32) if self.keep_acc else None
         o = P['out']

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HAWQ_ABI_VERSION 3
+#define HAWQ_ABI_VERSION 4
 
 const char *hawq_last_error(void);
 int hawq_abi_version(void);
@@ -128,6 +128,18 @@ typedef struct hawq_conv_args {
                     which clamps to its 16-bit range (quant_utils.py:409-413); with an identity (case 1) nothing clamps (:456).
        With res_in == NULL and in2 == NULL there is no identity branch: o = requant(acc + bias).                          */
     int32_t res_no_relu, res_clamp16;
+    /* ABI 4 - narrow tensors stored at their own width (MobileNetV2's 16 / 24 / 32 / 96 / 144 / 160-channel tensors,
+       q_mobilenetv2.py:36-58: in the reference they are exactly that wide; padding every one of them to the 64-channel tile
+       doubled to quadrupled the bytes of the early layers).
+       in_pitch:  bytes from one pixel row of `in` to the next; 0 = dense (Cin * in_bits / 8).  A pitch BELOW the dense row lets a
+                  tensor of Cin_valid <= in_pitch channels feed a conv whose K (Cin) is padded to 64: the 64-byte chunk reads run on
+                  into the following pixel's bytes, where they meet zero weights (integers: garbage x 0 = 0, exact).  Multiple of
+                  16, int8 operands, single branch, not planar, not the band kernels; the buffer must be readable 64 bytes past
+                  its last row.
+       out_pitch: channels per stored pixel row of out_q / res_out / res_in; 0 = Cout.  Channels >= out_pitch are not written
+                  at all; on the general path channels in [n_valid, out_pitch) are written as zeros.  Multiple of 16,
+                  REQUANT / RESIDUAL epilogues with NHWC rows (fast REQUANT, or the general path), single branch.           */
+    int32_t in_pitch, out_pitch;
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
