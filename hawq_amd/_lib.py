@@ -45,6 +45,12 @@ class ExpandReduceArgs(C.Structure):
     _fields_ = [("expand", ConvArgs), ("reduce", ConvArgs), ("tile", i32)]
 
 
+class BottleneckArgs(C.Structure):
+    """struct hawq_bottleneck_args (include/hawq_mi355.h): one launch per MobileNetV2 linear-bottleneck unit."""
+    _fields_ = [("expand", ConvArgs), ("project", ConvArgs), ("dw_wgt9c", vp), ("dw_ctab", vp),
+                ("dw_stride", i32), ("dw_q_lo", i32), ("dw_q_hi", i32), ("dw_fast_tables", i32), ("c_mid", i32), ("tile", i32)]
+
+
 # name -> (argtypes); every function returns int except hawq_last_error
 SIGNATURES = {
     "hawq_abi_version": [],
@@ -55,6 +61,8 @@ SIGNATURES = {
     "hawq_conv2d_band_tile": [C.POINTER(ConvArgs)],
     "hawq_conv_expand_reduce": [C.POINTER(ExpandReduceArgs), vp],
     "hawq_conv_expand_reduce_variants": [C.POINTER(ExpandReduceArgs)],
+    "hawq_linear_bottleneck": [C.POINTER(BottleneckArgs), vp],
+    "hawq_linear_bottleneck_ok": [C.POINTER(BottleneckArgs)],
     "hawq_quantize_input": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "hawq_stem_conv7": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_stem_fused": [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32,

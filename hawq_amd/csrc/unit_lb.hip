@@ -1,0 +1,295 @@
+// One launch per MobileNetV2 linear-bottleneck unit (round 4).
+//
+// Reference path: Q_LinearBottleneck.forward (q_mobilenetv2.py:59-93): quant_act -> conv1 1x1 (+ReLU6 + quant_act1) -> conv2 depthwise
+// 3x3 (+ReLU6 + quant_act2) -> conv3 1x1 -> quant_act_int32 (identity branch or not); the next unit's block-input QuantAct rides along
+// as it does on hawq_conv2d's RESIDUAL epilogue.
+//
+// Why: as three launches the unit writes and re-reads its expanded ("hidden") tensor twice - 6x the width of what enters and leaves the
+// unit.  On the 112 x 112 and 56 x 56 maps those two tensors ARE the unit's HBM traffic (profiles/r04_e_mbv2_perop_compact_gfast.txt:
+// units 1-4 are 45 % of the network's launch time).  Here a workgroup owns an 8 x 16 tile of output pixels of one image and walks the
+// hidden channels 32 at a time:
+//   GEMM1   window pixels (the tile's (7 S + 3) x (15 S + 3) halo window, 32 per MFMA block) x K = Cin (<= 64, one or two
+//           v_mfma_i32_32x32x32_i8) x 32 hidden channels; lane = pixel, 16 registers = 16 consecutive channels (cperm), requantised
+//           with the fused per-channel constants (3 instructions) and written to LDS as int8 [window pixel][32]; pixels outside the
+//           image become the depthwise conv's zero padding.  The 1x1 conv is recomputed on the halo (x 1.4 at stride 1) - it is K <= 64.
+//   DW      thread = (4 channels, one output column, 4 output rows): the rows' taps come out of LDS once (6 / 9 window rows of 3
+//           dwords), one v_dot4_i32_i8 per MAC against byte-masked weight dwords (as hawq_depthwise3x3_requant), requant, int8
+//           [output pixel][32] to LDS.  A wave's lanes cover 8 adjacent pixels x 32 channels: contiguous LDS rows.
+//   GEMM2   the 128 output pixels (one 32-pixel block per wave) x K = these 32 hidden channels x Cout (<= 64), accumulated in
+//           registers over all slices.
+//   closing the direct RESIDUAL arithmetic of hawq_conv2d (conv_igemm.hip, ConvP.gfast): per-channel requant + identity requant, no
+//           ReLU, 16-bit clamp without an identity, the next QuantAct; int32 carrier and int8 q leave as 64 / 16 bytes per lane.
+// Two workgroup barriers per slice; weights and table slices are read straight from L2 (a few KiB per unit).
+// HBM bytes per unit = its input + its outputs (+ the identity), e.g. unit 2 (16 -> 96 -> 24, 112^2 -> 56^2, batch 128): 26 MB in,
+// 10 MB out against 360 MB through the three launches.
+#include "common.h"
+
+namespace {
+
+struct LbP {
+    const int8_t *x;
+    int N, H, W, Ho, Wo, in_pitch;
+    const int8_t *w1;
+    int w1_pitch;
+    const int32_t *ct1;
+    int lo1, hi1;
+    const int8_t *w9;
+    int w9_pitch;
+    const int32_t *ct2;
+    int lo2, hi2;
+    const int8_t *w3;
+    int w3_pitch;
+    const int32_t *ct3;
+    int nsl;
+    const int32_t *res_in;
+    int m_id, e_id;
+    int32_t *res_out;
+    int8_t *out_q;
+    int mq, eq, q_lo, q_hi, clamp16, out_pitch;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ v4i ldg4(const void *p) { return *reinterpret_cast<const v4i *>(p); }
+
+__device__ __forceinline__ DyNt entry(const v4i t4) {
+    DyNt d;
+    d.m = t4.x, d.s = t4.y & 31, d.k = t4.y >> 8;
+    d.add = (long long)(((unsigned long long)(unsigned)t4.w << 32) | (unsigned)t4.z);
+    return d;
+}
+
+template <bool TIE>
+__device__ __forceinline__ int requant(int v, const DyNt &d) {
+    return TIE ? dyadic_tie(v, d) : dyadic_nt(v, d);
+}
+
+constexpr int LB_TH = 8, LB_TW = 16, LB_NT = 256;
+
+// S: depthwise stride; KS1: 32-byte K steps of the expand conv (Cin <= 32 KS1); CT2: 32-channel blocks of the projection's output
+template <int S, int KS1, int CT2, bool TIE>
+__global__ __launch_bounds__(LB_NT) void linear_bottleneck_kernel(const LbP p) {
+    constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WP = WH * WW, NB1 = (WP + 31) / 32, MAXB1 = (NB1 + 3) / 4;
+    constexpr int NR = 3 * S + 3;   // window rows under 4 vertically adjacent outputs
+    __shared__ __attribute__((aligned(16))) char hid[NB1 * 32 * 32];
+    __shared__ __attribute__((aligned(16))) char dwo[LB_TH * LB_TW * 32];
+    __shared__ v4i cts[2][2][32];   // [slice parity][expand | depthwise][channel of the slice]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y, n = bid / p.tiles_y;
+    const int oy0 = ty * LB_TH, ox0 = tx * LB_TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int8_t *img = p.x + (size_t)n * p.H * p.W * p.in_pitch;
+
+    // this wave's window blocks: the expand conv's B operand (lane = pixel, half h = bytes 16 h .. 16 h + 15 of each 32-byte K step)
+    v4i xw[MAXB1][KS1];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < MAXB1; ++i) {
+        const int blk = wave + 4 * i, wp = blk * 32 + l31;
+        const int wy = wp / WW, wx = wp - wy * WW, iy = iy0 + wy, ix = ix0 + wx;
+        const bool ok = blk < NB1 && wp < WP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        vmask |= (ok ? 1u : 0u) << i;
+        const int8_t *src = img + (size_t)(ok ? iy * p.W + ix : 0) * p.in_pitch + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) xw[i][ks] = ldg4(src + ks * 32);
+    }
+    if (t < 32) cts[0][0][t] = ldg4(p.ct1 + t * 4);
+    else if (t < 64) cts[0][1][t - 32] = ldg4(p.ct2 + (t - 32) * 4);
+    v16i acc2[CT2];
+#pragma unroll
+    for (int c = 0; c < CT2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
+    // depthwise thread mapping: 4 channels cg, output column dx, output rows dy0 .. dy0 + 3
+    const int cg = t & 7, dx = (t >> 3) & 15, dy0 = (t >> 7) * 4;
+    __syncthreads();
+
+    for (int j = 0; j < p.nsl; ++j) {
+        const int par = j & 1;
+        if (j + 1 < p.nsl) {   // next slice's table rows (read two barriers from now)
+            if (t < 32) cts[par ^ 1][0][t] = ldg4(p.ct1 + ((j + 1) * 32 + t) * 4);
+            else if (t < 64) cts[par ^ 1][1][t - 32] = ldg4(p.ct2 + ((j + 1) * 32 + t - 32) * 4);
+        }
+        // ---------------------------------------------------------------- GEMM1 + quant_act1 -> hid
+        {
+            v4i wf[KS1];
+            const int8_t *wr = p.w1 + (size_t)(j * 32 + cperm(l31)) * p.w1_pitch + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) wf[ks] = ldg4(wr + ks * 32);
+#pragma unroll
+            for (int i = 0; i < MAXB1; ++i) {
+                const int blk = wave + 4 * i;
+                if (blk < NB1) {
+                    v16i a;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = 0;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) a = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks], xw[i][ks], a, 0, 0, 0);
+                    int pk[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int qv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            qv[k] = med3i(requant<TIE>(a[4 * g + k], entry(cts[par][0][h * 16 + 4 * g + k])), p.lo1, p.hi1);
+                        pk[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                    }
+                    const bool ok = (vmask >> i) & 1;   // outside the image: the depthwise conv's zero padding
+                    const v4i w = ok ? v4i{pk[0], pk[1], pk[2], pk[3]} : v4i{0, 0, 0, 0};
+                    *reinterpret_cast<v4i *>(hid + (blk * 32 + l31) * 32 + h * 16) = w;
+                }
+            }
+        }
+        __syncthreads();   // B1: hid complete
+        // ---------------------------------------------------------------- depthwise 3x3 + quant_act2 -> dwo
+        {
+            int wm[9][4];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int ww = *reinterpret_cast<const int *>(p.w9 + (size_t)tp * p.w9_pitch + j * 32 + cg * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wm[tp][k] = ww & (0xff << (8 * k));
+            }
+            int acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] = 0;
+            const char *base = hid + ((dy0 * S) * WW + dx * S) * 32 + cg * 4;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                int r[3];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) r[kw] = *reinterpret_cast<const int *>(base + (rr * WW + kw) * 32);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int kh = rr - i * S;   // compile-time after unrolling
+                    if (kh >= 0 && kh < 3) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[i][k] = __builtin_amdgcn_sdot4(r[kw], wm[kh * 3 + kw][k], acc[i][k], false);
+                    }
+                }
+            }
+            DyNt d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = entry(cts[par][1][cg * 4 + k]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int qv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) qv[k] = med3i(requant<TIE>(acc[i][k], d[k]), p.lo2, p.hi2);
+                *reinterpret_cast<int *>(dwo + ((dy0 + i) * LB_TW + dx) * 32 + cg * 4) = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+            }
+        }
+        __syncthreads();   // B2: dwo complete, hid free
+        // ---------------------------------------------------------------- GEMM2 partial sum over this slice
+        {
+            const v4i af = *reinterpret_cast<const v4i *>(dwo + (wave * 32 + l31) * 32 + h * 16);
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) {
+                const v4i wf = ldg4(p.w3 + (size_t)(c * 32 + cperm(l31)) * p.w3_pitch + j * 32 + h * 16);
+                acc2[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc2[c], 0, 0, 0);
+            }
+        }
+    }
+
+    // -------------------------------------------------------------------- closing: quant_act_int32 (+ identity), next QuantAct
+    const int pl = wave * 32 + l31, gy = oy0 + (pl >> 4), gx = ox0 + (pl & 15);
+    if (gy >= p.Ho || gx >= p.Wo) return;
+    const size_t pix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
+    const DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);
+#pragma unroll
+    for (int c = 0; c < CT2; ++c) {
+        const int ch = c * 32 + h * 16;
+        if (ch >= p.out_pitch) continue;
+        const size_t elem = pix * p.out_pitch + ch;
+        int qw[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4i rin = {0, 0, 0, 0};
+            if (p.res_in) rin = ldg4(p.res_in + elem + 4 * g);
+            int o[4], qv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int ov = requant<TIE>(acc2[c][4 * g + k], entry(ldg4(p.ct3 + (size_t)(ch + 4 * g + k) * 4)));
+                if (p.res_in) ov += requant<TIE>(rin[k], dids);
+                if (p.clamp16) ov = clampi(ov, -32768, 32767);
+                o[k] = ov;
+                qv[k] = clampi(requant<TIE>(ov, dq), p.q_lo, p.q_hi);
+            }
+            if (p.res_out) *reinterpret_cast<v4i *>(p.res_out + elem + 4 * g) = v4i{o[0], o[1], o[2], o[3]};
+            qw[g] = (int)pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+        }
+        if (p.out_q) *reinterpret_cast<v4i *>(p.out_q + elem) = v4i{qw[0], qw[1], qw[2], qw[3]};
+    }
+}
+
+typedef void (*LbFn)(const LbP);
+template <int S, int KS1, int CT2>
+LbFn pick_tie(bool tie) {
+    return tie ? linear_bottleneck_kernel<S, KS1, CT2, true> : linear_bottleneck_kernel<S, KS1, CT2, false>;
+}
+template <int S>
+LbFn pick(int ks1, int ct2, bool tie) {
+    if (ks1 == 1) return ct2 == 1 ? pick_tie<S, 1, 1>(tie) : pick_tie<S, 1, 2>(tie);
+    return ct2 == 1 ? pick_tie<S, 2, 1>(tie) : pick_tie<S, 2, 2>(tie);
+}
+
+bool e_fast(int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; }
+
+// nullptr when the launch takes the unit, else why not
+const char *lb_refusal(const hawq_bottleneck_args *a) {
+    const hawq_conv_args &e = a->expand, &q = a->project;
+    if (!e.in || !e.wgt || !e.ctab || !q.wgt || !q.ctab || !a->dw_wgt9c || !a->dw_ctab) return "null pointer (in / wgt / ctab of the three layers)";
+    if (e.N <= 0 || e.H <= 0 || e.W <= 0) return "empty input";
+    if (e.KH != 1 || e.KW != 1 || e.stride != 1 || e.pad != 0 || q.KH != 1 || q.KW != 1 || q.stride != 1 || q.pad != 0) return "conv1 / conv3 must be 1x1, stride 1";
+    if (e.in_bits != 8 || e.w_bits != 8 || q.in_bits != 8 || q.w_bits != 8 || e.in2 || q.in2 || e.in_planar || q.out_planar) return "int8 NHWC single-branch layers only";
+    if (e.epilogue != HAWQ_EPI_REQUANT || !e.fast_tables || !e.relu) return "expand: REQUANT epilogue with ReLU and fast_tables";
+    if (q.epilogue != HAWQ_EPI_RESIDUAL || !q.fast_tables || !q.res_no_relu) return "project: signed RESIDUAL epilogue (res_no_relu) with fast_tables";
+    if (!a->dw_fast_tables || (a->dw_stride != 1 && a->dw_stride != 2)) return "depthwise: fast tables, stride 1 or 2";
+    if (e.Cin != 64 || (e.in_pitch != 0 && e.in_pitch != 16 && e.in_pitch != 32 && e.in_pitch != 64)) return "expand: K = 64 packed weights, in_pitch 16 / 32 / 64";
+    if (e.Cout <= 0 || e.Cout % 64 || q.Cin != e.Cout || a->c_mid <= 0 || a->c_mid > e.Cout) return "hidden width: expand.Cout == project.Cin, a multiple of 64, c_mid inside it";
+    if (q.Cout != 64 || (q.out_pitch != 0 && q.out_pitch != 16 && q.out_pitch != 32 && q.out_pitch != 64)) return "project: Cout = 64 packed rows, out_pitch 16 / 32 / 64";
+    if (e.q_hi < 0 || e.q_hi > 127 || a->dw_q_lo < 0 || a->dw_q_hi < a->dw_q_lo || a->dw_q_hi > 127) return "hidden activations must be 0 .. 127 int8 (ReLU in the clamp)";
+    if (q.out_q && (q.out_bits != 8 || q.q_lo < -128 || q.q_hi > 127 || q.q_lo > q.q_hi || q.mq < 0 || !e_fast(q.eq))) return "project: int8 out_q with a fast (mq, eq)";
+    if (q.res_in && (q.res_in_bits != 32 || q.m_id_scalar < 0 || !e_fast(q.e_id_scalar) || a->dw_stride != 1)) return "identity: int32 carrier, fast scalar table, stride 1";
+    if (q.res_out && q.res_out_bits != 32) return "res_out must be the int32 carrier";
+    if (!q.out_q && !q.res_out) return "nothing to write";
+    const int H = e.H, W = e.W, Ho = (H - 1) / a->dw_stride + 1, Wo = (W - 1) / a->dw_stride + 1;
+    if (q.N != e.N || q.H != Ho || q.W != Wo) return "project geometry must be the depthwise conv's output grid";
+    if ((long long)e.N * ((Ho + LB_TH - 1) / LB_TH) * ((Wo + LB_TW - 1) / LB_TW) > 0x7fffffffll) return "grid too large";
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" int hawq_linear_bottleneck_ok(const hawq_bottleneck_args *a) { return a && lb_refusal(a) == nullptr ? 1 : 0; }
+
+extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *stream) {
+    HAWQ_REQUIRE(a, "hawq_linear_bottleneck: null args");
+    const char *why = lb_refusal(a);
+    HAWQ_REQUIRE(!why, "hawq_linear_bottleneck: %s", why);
+    const hawq_conv_args &e = a->expand, &q = a->project;
+    LbP p;
+    p.x = (const int8_t *)e.in;
+    p.N = e.N, p.H = e.H, p.W = e.W, p.Ho = q.H, p.Wo = q.W;
+    p.in_pitch = e.in_pitch ? e.in_pitch : 64;
+    p.w1 = (const int8_t *)e.wgt, p.w1_pitch = e.Cin, p.ct1 = e.ctab, p.lo1 = e.q_lo < 0 ? 0 : e.q_lo, p.hi1 = e.q_hi;
+    p.w9 = a->dw_wgt9c, p.w9_pitch = e.Cout, p.ct2 = a->dw_ctab, p.lo2 = a->dw_q_lo, p.hi2 = a->dw_q_hi;
+    p.w3 = (const int8_t *)q.wgt, p.w3_pitch = q.Cin, p.ct3 = q.ctab;
+    p.nsl = (a->c_mid + 31) / 32;
+    p.res_in = (const int32_t *)q.res_in, p.m_id = q.res_in ? q.m_id_scalar : 0, p.e_id = q.res_in ? q.e_id_scalar : 33;
+    p.res_out = (int32_t *)q.res_out, p.out_q = (int8_t *)q.out_q;
+    p.mq = q.out_q ? q.mq : 0, p.eq = q.out_q ? q.eq : 33, p.q_lo = q.q_lo, p.q_hi = q.q_hi, p.clamp16 = q.res_clamp16;
+    p.out_pitch = q.out_pitch ? q.out_pitch : 64;
+    p.tiles_x = (p.Wo + LB_TW - 1) / LB_TW, p.tiles_y = (p.Ho + LB_TH - 1) / LB_TH;
+    const bool tie = ((e.fast_tables | a->dw_fast_tables | q.fast_tables) & 4) != 0;
+    const int ks1 = p.in_pitch <= 32 ? 1 : 2, ct2 = p.out_pitch <= 32 ? 1 : 2;
+    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie) : pick<2>(ks1, ct2, tie);
+    hipLaunchKernelGGL(fn, dim3(p.N * p.tiles_y * p.tiles_x), dim3(LB_NT), 0, (hipStream_t)stream, p);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -127,6 +127,9 @@ class _Layer:
             w9c = np.zeros((9, self.cout_s), np.int8)   # tap-major [3][3][C] with C = the stored width of the tensors it runs on
             w9c[:, :self.cout] = w.reshape(self.cout, 9).T
             self.w = torch.from_numpy(w9c).to(dev)
+            w9p = np.zeros((9, self.cout_p), np.int8)   # the one-launch unit reads whole 32-channel slices (hawq_linear_bottleneck)
+            w9p[:, :self.cout] = w9c[:, :self.cout]
+            self.w9p = torch.from_numpy(w9p).to(dev)
         else:
             raise NotImplementedError("grouped convolutions other than depthwise 3x3 are outside MobileNetV2")
 
@@ -245,6 +248,17 @@ class MobileNetV2Engine:
                     ent['ctab'] = _i32(packing.pack_ctab(_padded(layer.b_host, cp), _padded(mm, cp), _padded(ee, cp, 33)), dev)
                     ent['m'], ent['e'] = _i32(_padded(mm, cp), dev), _i32(_padded(ee, cp, 33), dev)
                     ent['fast'] = 1 if tables_are_fast(mm, ee, layer.vbits) else 5
+            else:
+                # depthwise: the same contract for the one-launch unit (hawq_linear_bottleneck); hawq_depthwise3x3_requant keeps (m, e)
+                try:
+                    mm, ee = requant_table(s_a, layer.s_w, s_o, vbits=layer.vbits)
+                    fits = tables_fit_fast(mm, ee, layer.vbits)
+                except ValueError:
+                    fits = False
+                if fits:
+                    cp = layer.cout_p
+                    ent['dw_ctab'] = _i32(packing.pack_ctab(_padded(layer.b_host, cp), _padded(mm, cp), _padded(ee, cp, 33)), dev)
+                    ent['dw_fast'] = 1 if tables_are_fast(mm, ee, layer.vbits) else 5
             return ent
 
         # init block: conv -> ReLU6 -> quant_act_int32 (16 bit)
@@ -332,6 +346,25 @@ class MobileNetV2Engine:
         a.out_pitch = L.cout_s if L.cout_s != L.cout_p else 0   # (RAW taps reset it: the accumulators are dense [M][Cout])
         return a
 
+    def _one_launch(self, u, nq_fast) -> bool:
+        """Does this unit run as one hawq_linear_bottleneck launch?  Needs: conv1 1x1 + depthwise 3x3 + conv3 1x1 with every requant
+        table proved for the fast contract, block input and output at most 64 channels wide (the launch keeps the projection's
+        accumulators of an 8 x 16 pixel tile in registers).  HAWQ_MBV2_UNFUSED=1: three launches per unit everywhere (A/B switch);
+        tapped plans (keep_accumulators) always run the three launches - the taps ARE the intermediate tensors."""
+        if self.keep_acc or os.environ.get("HAWQ_MBV2_UNFUSED") or os.environ.get("HAWQ_MBV2_EXACT") or os.environ.get("HAWQ_MBV2_PAD64"):
+            return False
+        if len(u['layers']) != 2:
+            return False
+        e1, e2 = u['layers']
+        L1, L2, L3 = e1['layer'], e2['layer'], u['proj']['layer']
+        if L1.groups != 1 or (L1.kh, L1.kw, L1.stride) != (1, 1, 1) or L2.groups == 1 or (L3.kh, L3.kw, L3.stride) != (1, 1, 1):
+            return False
+        if not e1.get('fast') or 'dw_ctab' not in e2 or u['proj']['fast'] is None or nq_fast is None:
+            return False
+        if u['residual'] and u.get('id_fast') is None:
+            return False
+        return L1.cin_p == 64 and L3.cout_p == 64 and L1.cin_s in (16, 32, 64) and L3.cout_s in (16, 32, 64) and e1['hi'] <= 127 and e2['hi'] <= 127
+
     def _tap(self, ops, keep, name, a, N, ho, wo, cout, cout_p):
         """extra RAW launch exposing the conv's int32 accumulators (tests only)"""
         acc = torch.empty(N * ho * wo * cout_p, dtype=torch.int32, device=self.dev)
@@ -409,6 +442,7 @@ class MobileNetV2Engine:
         ops, keep, self.taps, self._graph = [], [], {}, None
         self._convs, self._tuned = [], False   # hawq_conv2d argument structs of the plan (tile autotuning)
         self.n_fast = 0
+        self.n_fused_units = 0    # units that run as ONE launch (hawq_linear_bottleneck)
         self.n_fast_closing = 0   # unit-closing launches whose tables are all proved: the direct epilogue with 3-instruction requants
         self.plan_bytes = N * 3 * H * W * 4   # bytes the plan has to move at the networks' true widths (no padding channels)
         # 64 elements of slack: a conv that reads a narrow tensor through in_pitch fetches up to 48 bytes past the last pixel row
@@ -432,17 +466,21 @@ class MobileNetV2Engine:
             ops.append(partial(_lib.call, "hawq_f32_nchw_to_q_nhwc", xq_f.data_ptr(), xq.data_ptr(), N, 3, H, W, init.cin_p, 8, P['s_in'], sp))
             keep += [xq_f, xq]
 
-        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True, fast=None, id_fast=None, q_fast=None):
+        def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True, fast=None, id_fast=None, q_fast=None,
+                    unit=None):
             """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo);
-            the 32-bit carrier is only written where something reads it (the next unit's identity, the pool, a tap)"""
+            the 32-bit carrier is only written where something reads it (the next unit's identity, the pool, a tap).
+            ``unit`` = dict(x, h, w, conv1 entry, conv2 entry): the whole unit as ONE launch (hawq_linear_bottleneck) - x is then the
+            unit's block input and (h, w) the depthwise conv's output grid"""
             ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
-            a = self._conv_args(L, x, n, h, w)
+            a = self._conv_args(L, x if unit is None else unit['x'], n, h, w)
             a.epilogue, a.m, a.e = _lib.EPI_RESIDUAL, m.data_ptr(), e.data_ptr()
             out16 = None
             if need16 or self.keep_acc:
                 out16 = alloc(n * ho * wo * L.cout_s, torch.int32)
                 a.res_out, a.res_out_bits = out16.data_ptr(), 32
-            self.plan_bytes += n * (h * w * L.cin + ho * wo * L.cout * ((4 if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
+            in_bytes = h * w * L.cin if unit is None else unit['h'] * unit['w'] * unit['e1']['layer'].cin   # (the hidden tensors stay on chip)
+            self.plan_bytes += n * (in_bytes + ho * wo * L.cout * ((4 if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
             use_fast = (fast is not None and (res_in is None or id_fast is not None) and (nxt_q is None or q_fast is not None)
                         and not os.environ.get("HAWQ_MBV2_EXACT"))
             if res_in is not None:
@@ -466,8 +504,28 @@ class MobileNetV2Engine:
             if self.keep_acc:
                 self._tap(ops, keep, name, a, n, ho, wo, L.cout, L.cout_p)
             keep.extend([a, out16, q])
-            self._convs.append((name, a))
-            ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+            if unit is not None:
+                if not use_fast:
+                    raise RuntimeError("one-launch unit without proved tables (plan logic error)")
+                e1, e2 = unit['e1'], unit['e2']
+                L1, L2 = e1['layer'], e2['layer']
+                b = _lib.BottleneckArgs()
+                x1 = self._conv_args(L1, unit['x'], n, unit['h'], unit['w'])
+                x1.epilogue, x1.relu, x1.q_lo, x1.q_hi, x1.out_bits = _lib.EPI_REQUANT, 1, e1['lo'], e1['hi'], 8
+                x1.fast_tables, x1.ctab, x1.out_pitch = e1['fast'], e1['ctab'].data_ptr(), 0
+                C.memmove(C.byref(b.expand), C.byref(x1), C.sizeof(x1))
+                C.memmove(C.byref(b.project), C.byref(a), C.sizeof(a))
+                b.dw_wgt9c, b.dw_ctab = L2.w9p.data_ptr(), e2['dw_ctab'].data_ptr()
+                b.dw_stride, b.dw_q_lo, b.dw_q_hi, b.dw_fast_tables, b.c_mid = L2.stride, e2['lo'], e2['hi'], e2['dw_fast'], L2.cout
+                if not _lib.load().hawq_linear_bottleneck_ok(C.byref(b)):
+                    raise RuntimeError("hawq_linear_bottleneck refuses a unit the plan selected for it")
+                keep.append(b)
+                self.plan_bytes += L1.weight_bytes + L2.weight_bytes
+                self.n_fused_units += 1
+                ops.append(partial(_lib.call, "hawq_linear_bottleneck", C.byref(b), sp))
+            else:
+                self._convs.append((name, a))
+                ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
             if out16 is not None:
                 self.taps[name + ":out16"] = (out16, (n, ho, wo, L.cout_s), L.cout)
             if q is not None:
@@ -481,6 +539,18 @@ class MobileNetV2Engine:
         for ui, u in enumerate(units):
             name = f"unit{ui + 1}"
             x = q
+            nxt = units[ui + 1] if ui + 1 < len(units) else None
+            nq = (nxt['mq'], nxt['eq'], nxt['q_rng']) if nxt is not None else (P['before_final']['mq'], P['before_final']['eq'], P['before_final']['rng'])
+            nq_fast = nxt['q_fast'] if nxt is not None else P['before_final']['q_fast']
+            pr = u['proj']
+            if self._one_launch(u, nq_fast):
+                e1, e2 = u['layers']
+                s2 = e2['layer'].stride
+                ho, wo = (h - 1) // s2 + 1, (w - 1) // s2 + 1
+                x16, q, h, w = closing(pr['layer'], pr['m'], pr['e'], None, N, ho, wo, x16 if u['residual'] else None, u.get('m_id', 0), u.get('e_id', 33),
+                                       False, not u['residual'], nq, name + ".conv3", need16=bool(nxt is not None and nxt['residual']),
+                                       fast=pr['fast'], id_fast=u.get('id_fast'), q_fast=nq_fast, unit=dict(x=x, h=h, w=w, e1=e1, e2=e2))
+                continue
             for li, ent in enumerate(u['layers']):
                 L = ent['layer']
                 ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
@@ -512,10 +582,6 @@ class MobileNetV2Engine:
                 self.taps[lname + ":q"] = (out, (N, ho, wo, L.cout_s), L.cout)
                 keep.append(out)
                 x, h, w = out, ho, wo
-            nxt = units[ui + 1] if ui + 1 < len(units) else None
-            nq = (nxt['mq'], nxt['eq'], nxt['q_rng']) if nxt is not None else (P['before_final']['mq'], P['before_final']['eq'], P['before_final']['rng'])
-            nq_fast = nxt['q_fast'] if nxt is not None else P['before_final']['q_fast']
-            pr = u['proj']
             x16, q, h, w = closing(pr['layer'], pr['m'], pr['e'], x, N, h, w, x16 if u['residual'] else None, u.get('m_id', 0), u.get('e_id', 33),
                                    False, not u['residual'], nq, name + ".conv3", need16=bool(nxt is not None and nxt['residual']),
                                    fast=pr['fast'], id_fast=u.get('id_fast'), q_fast=nq_fast)

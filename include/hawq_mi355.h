@@ -278,6 +278,34 @@ int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32
                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t C_valid, int32_t stride, int32_t relu, int32_t q_lo,
                               int32_t q_hi, int8_t *out_q, int32_t *out_acc, void *stream);
 
+/* One launch per linear-bottleneck unit of MobileNetV2 (Q_LinearBottleneck.forward, q_mobilenetv2.py:59-93; round 4):
+ *   block-input int8 -> conv1 1x1 (+ReLU6 + quant_act1) -> conv2 depthwise 3x3 / stride 1|2 / pad 1 (+ReLU6 + quant_act2)
+ *   -> conv3 1x1 -> quant_act_int32 (with / without the identity branch) -> the next block-input QuantAct,
+ * the expanded ("hidden") tensor never leaves the CU: a workgroup owns an 8 x 16 tile of OUTPUT pixels of one image, recomputes the
+ * 1x1 expand conv on the tile's halo window, runs the depthwise taps out of LDS and feeds the projection GEMM from LDS, 32 hidden
+ * channels at a time.  Same integers as the three launches (hawq_conv2d REQUANT, hawq_depthwise3x3_requant, hawq_conv2d RESIDUAL).
+ *   expand:  as for hawq_conv2d with the REQUANT epilogue and fast_tables != 0 (ctab, q_lo / q_hi, relu = 1); 1x1 / stride 1; Cin is the
+ *            K of its packed weights (64), in_pitch in {16, 32} or dense 64; Cout = the hidden width padded to 64; out_q is ignored.
+ *   dw_*:    wgt9c [9][expand.Cout] int8 tap-major (zero beyond the real channels); dw_ctab [expand.Cout][4] fused constants of its
+ *            requant with the bias folded in (hawq_amd.packing.pack_ctab); dw_fast_tables as hawq_conv_args.fast_tables (1, or 5 = exact
+ *            ties); clamp [dw_q_lo >= 0 (ReLU), dw_q_hi <= 127].
+ *   project: as for hawq_conv2d with the RESIDUAL epilogue on the direct form: fast_tables != 0 (ctab), res_no_relu = 1, res_clamp16,
+ *            res_in (int32, optional identity: then H x W, stride 1, out_pitch == expand's in_pitch), res_out (int32, optional), out_q
+ *            int8 (optional), mq / eq / q_lo / q_hi; Cin == expand.Cout; out_pitch in {16, 32} or dense 64 (Cout = 64); `in` is ignored.
+ *   c_mid:   real hidden channels (channels >= c_mid of every hidden-side table / weight are zero padding).
+ * hawq_linear_bottleneck_ok: 1 when this launch takes the unit as described, else 0 (use the three launches). */
+typedef struct hawq_bottleneck_args {
+    hawq_conv_args expand;
+    hawq_conv_args project;
+    const int8_t *dw_wgt9c;
+    const int32_t *dw_ctab;
+    int32_t dw_stride, dw_q_lo, dw_q_hi, dw_fast_tables;
+    int32_t c_mid;
+    int32_t tile;   /* 0 = default; reserved for variants */
+} hawq_bottleneck_args;
+int hawq_linear_bottleneck(const hawq_bottleneck_args *args, void *stream);
+int hawq_linear_bottleneck_ok(const hawq_bottleneck_args *args);
+
 /* Input QuantAct + im2col for a 3x3 / stride 2 / pad 1 first conv on 3 channels (MobileNetV2's init block, q_mobilenetv2.py:182-186
  * after quant_modules.py:271-274): x fp32 [N][3][H][W] -> out int8 [N][Ho][Wo][64], row = the 27 values
  * clamp(rne(inv_scale * x), q_lo, q_hi) of the output pixel's patch in (kh, kw, c) order (zero outside the image), then 37 zeros.

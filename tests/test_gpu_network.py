@@ -391,6 +391,36 @@ def test_mobilenetv2_concurrent_sub_batches_are_bit_identical():
             assert len(eng.subs) == 2 and [s._batch[0] for s in eng.subs] == [11, 10]
 
 
+@pytest.mark.parametrize("scheme", ["uniform8", "bops_0.5"])
+@pytest.mark.parametrize("hw", [(224, 224), (72, 104)])
+def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, monkeypatch):
+    """hawq_linear_bottleneck (one launch per unit: expand 1x1 -> depthwise 3x3 -> project 1x1 + quant_act_int32 + next QuantAct, the
+    hidden tensors never leaving the CU) against the three launches it replaces: every unit-closing tensor (int8 block input of the next
+    unit, int32 carrier where one is written) and the logits bit for bit - on the full 224 x 224 maps and on an odd geometry whose
+    tiles hang over every edge (36 x 52 -> 18 x 26 -> 9 x 13 -> 5 x 7 -> 3 x 4 maps)."""
+    from hawq_amd.api import build_quantized_model, calibrate
+    from hawq_amd.engine_mbv2 import MobileNetV2Engine
+    from hawq_amd.skeleton import synthetic_images
+    model = build_quantized_model("mobilenetv2_w1", scheme, seed=0).cuda()
+    calibrate(model, _images().cuda())
+    x = (synthetic_images(3, seed=9) * 1.1).cuda()
+    if hw != (224, 224):
+        x = torch.nn.functional.interpolate(x, size=hw, mode="bilinear", align_corners=False).contiguous()
+    monkeypatch.setenv("HAWQ_MBV2_UNFUSED", "1")
+    three = MobileNetV2Engine(model, chains=1, use_graph=False)
+    y3 = three(x).clone()
+    assert three.n_fused_units == 0
+    monkeypatch.delenv("HAWQ_MBV2_UNFUSED")
+    one = MobileNetV2Engine(model, chains=1, use_graph=False)
+    y1 = one(x).clone()
+    assert one.n_fused_units >= 7, one.n_fused_units   # units 1-10 of the width-1 network have <= 64-channel inputs and outputs
+    assert len(one._ops) == len(three._ops) - 2 * one.n_fused_units
+    for name in sorted(one.taps):
+        if name.endswith(":next_q") or name.endswith(":out16"):
+            assert np.array_equal(one.tap(name), three.tap(name)), name
+    assert torch.equal(y1, y3)
+
+
 def test_mobilenetv2_uint8_input_equals_the_normalised_tensor_path():
     """MobileNetV2Engine.forward_uint8 (hawq_quantize_im2col3x3s2_u8: ToTensor + Normalize + input QuantAct as a table look-up
     feeding the init conv's im2col rows) == the fp32 path on the tensor the reference's pipeline builds (quant_train.py:428-440),

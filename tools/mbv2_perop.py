@@ -32,10 +32,14 @@ with torch.cuda.stream(eng.stream):
         if name in ("hawq_conv2d",):
             a = op.args[1]._obj
             extra = f"M={a.N * a.H * a.W // (a.stride * a.stride)} Cin={a.Cin} Cout={a.Cout} k={a.KH} s={a.stride} epi={a.epilogue} tile={a.tile} fast={a.fast_tables} n_valid={a.n_valid}"
+        elif name == "hawq_linear_bottleneck":
+            b = op.args[1]._obj
+            extra = (f"N={b.expand.N} {b.expand.H}x{b.expand.W} in_pitch={b.expand.in_pitch or 64} hidden={b.c_mid} stride={b.dw_stride} "
+                     f"out_pitch={b.project.out_pitch or 64} identity={int(bool(b.project.res_in))} carrier={int(bool(b.project.res_out))}")
         elif name == "hawq_depthwise3x3_requant":
             _, _x, _w, _b, _m, _e, n, h, w, c, cv, s = op.args[:12]
             extra = f"N={n} {h}x{w} C={c} (valid {cv}) stride={s}"
         rows.append((i, name, us, extra))
 for i, name, us, extra in rows:
     print(f"{i:3d} {name:28s} {us:7.1f} us  {extra}")
-print(f"sum of launches {total:.1f} us for batch {N} (one chain); tiles {eng.tile_choice}")
+print(f"sum of launches {total:.1f} us for batch {N} (one chain); {eng.n_fused_units} one-launch units; tiles {eng.tile_choice}")
