@@ -19,10 +19,11 @@
 //           registers over all slices.
 //   closing the direct RESIDUAL arithmetic of hawq_conv2d (conv_igemm.hip, ConvP.gfast): per-channel requant + identity requant, no
 //           ReLU, 16-bit clamp without an identity, the next QuantAct; int32 carrier and int8 q leave as 64 / 16 bytes per lane.
-// Two workgroup barriers per slice; weights and table slices are read straight from L2 (a few KiB per unit).
+// Two workgroup barriers per slice; weights and table slices are staged through LDS one slice ahead (a few KiB per slice, from L2).
 // HBM bytes per unit = its input + its outputs (+ the identity), e.g. unit 2 (16 -> 96 -> 24, 112^2 -> 56^2, batch 128): 26 MB in,
 // 10 MB out against 360 MB through the three launches.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -65,15 +66,36 @@ __device__ __forceinline__ int requant(int v, const DyNt &d) {
 
 constexpr int LB_TH = 8, LB_TW = 16, LB_NT = 256;
 
-// S: depthwise stride; KS1: 32-byte K steps of the expand conv (Cin <= 32 KS1); CT2: 32-channel blocks of the projection's output
+// S: depthwise stride; KS1: 32-byte K steps of the expand conv (Cin <= 32 KS1); CT2: 32-channel blocks of the projection's output.
+// Everything a slice needs besides activations - its 32 + 32 table rows, the W1 rows, the 9 depthwise tap rows and the W3 columns
+// (3.3 .. 5.3 KiB) - is staged through LDS one slice ahead: each thread fetches at most two 16-byte items at the top of slice j
+// and stores them between the two barriers of that slice, so that no global-memory latency sits on the per-slice dependency chain
+// (the first version read them where they were used: ~2.8 us per slice on the 14 x 14 units, 12 slices each).
+// register budget = waves per SIMD the compiler must leave room for (stride 1 / stride 2 instantiations); measured on the ten fused
+// units of MobileNetV2 w1 at batch 128: unconstrained 981 us, 4 / 3 973 us (spills), 3 / 2 924 us (profiles/r04_e_mbv2_unit_occupancy.txt)
+#ifndef LB_OCC1
+#define LB_OCC1 3
+#define LB_OCC2 2
+#endif
+#if LB_OCC1
+#define LB_OCC_ATTR __attribute__((amdgpu_waves_per_eu(S == 1 ? LB_OCC1 : LB_OCC2)))
+#else
+#define LB_OCC_ATTR
+#endif
 template <int S, int KS1, int CT2, bool TIE>
-__global__ __launch_bounds__(LB_NT) void linear_bottleneck_kernel(const LbP p) {
-    constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WP = WH * WW, NB1 = (WP + 31) / 32, MAXB1 = (NB1 + 3) / 4;
+__global__ __launch_bounds__(LB_NT) LB_OCC_ATTR void linear_bottleneck_kernel(const LbP p) {
+    constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WP = WH * WW, NB1 = (WP + 31) / 32;
     constexpr int NR = 3 * S + 3;   // window rows under 4 vertically adjacent outputs
-    __shared__ __attribute__((aligned(16))) char hid[NB1 * 32 * 32];
+    constexpr int N_W1 = 64 * KS1, N_W9 = 18, N_W3 = 64 * CT2, N_ITEMS = 64 + N_W1 + N_W9 + N_W3;   // 16-byte items per slice
+    constexpr int OFF_CT1 = 0, OFF_CT2 = 512, OFF_W1 = 1024, OFF_W9 = OFF_W1 + 1024 * KS1, OFF_W3 = OFF_W9 + 288, BUF = OFF_W3 + 1024 * CT2;
+    static_assert(N_ITEMS <= 2 * LB_NT, "two items per thread");
+    __shared__ __attribute__((aligned(16))) char xs[NB1 * 32 * 32 * KS1];   // block input on the halo window [window pixel][K]
+    __shared__ __attribute__((aligned(16))) char hid[NB1 * 32 * 32];        // quant_act1 output [window pixel][32 channels of the slice]
     __shared__ __attribute__((aligned(16))) char dwo[LB_TH * LB_TW * 32];
-    __shared__ v4i cts[2][2][32];   // [slice parity][expand | depthwise][channel of the slice]
+    __shared__ __attribute__((aligned(16))) char stg[2][BUF];   // [slice parity]
+    __shared__ v4i ct3s[32 * CT2];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     int bid = blockIdx.x;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
@@ -81,21 +103,58 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_kernel(const LbP p) {
     const int oy0 = ty * LB_TH, ox0 = tx * LB_TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const int8_t *img = p.x + (size_t)n * p.H * p.W * p.in_pitch;
 
-    // this wave's window blocks: the expand conv's B operand (lane = pixel, half h = bytes 16 h .. 16 h + 15 of each 32-byte K step)
-    v4i xw[MAXB1][KS1];
+    // The expand conv's B operand (lane = pixel, half h = bytes 16 h .. 16 h + 15 of each 32-byte K step): the tile's halo window goes
+    // to LDS once (every slice's GEMM1 reads it again).  Requant work per wave: NOWN whole window blocks (wave, wave + 4, ..) and a
+    // quarter of the channels of the last two blocks (registers 4 wave .. 4 wave + 3 of both lane halves) - 6 / 18 blocks do not
+    // divide by 4 waves and the MFMA itself is free; vmask = which of this wave's pixels lie inside the image.
+    constexpr int NOWN = (NB1 - 2) / 4, NBW = NOWN + 2;
+    static_assert((NB1 - 2) % 4 == 0, "window blocks = 4 NOWN + 2");
     unsigned vmask = 0;
 #pragma unroll
-    for (int i = 0; i < MAXB1; ++i) {
-        const int blk = wave + 4 * i, wp = blk * 32 + l31;
+    for (int i = 0; i < NBW; ++i) {
+        const int blk = i < NOWN ? wave + 4 * i : NB1 - 2 + (i - NOWN), wp = blk * 32 + l31;
         const int wy = wp / WW, wx = wp - wy * WW, iy = iy0 + wy, ix = ix0 + wx;
-        const bool ok = blk < NB1 && wp < WP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const bool ok = wp < WP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         vmask |= (ok ? 1u : 0u) << i;
-        const int8_t *src = img + (size_t)(ok ? iy * p.W + ix : 0) * p.in_pitch + h * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) xw[i][ks] = ldg4(src + ks * 32);
     }
-    if (t < 32) cts[0][0][t] = ldg4(p.ct1 + t * 4);
-    else if (t < 64) cts[0][1][t - 32] = ldg4(p.ct2 + (t - 32) * 4);
+#pragma unroll
+    for (int i = 0; i < (NB1 + 3) / 4; ++i) {
+        const int blk = wave + 4 * i, wp = blk * 32 + l31;
+        if (blk < NB1) {
+            const int wy = wp / WW, wx = wp - wy * WW, iy = iy0 + wy, ix = ix0 + wx;
+            const bool ok = wp < WP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int8_t *src = img + (size_t)(ok ? iy * p.W + ix : 0) * p.in_pitch + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) *reinterpret_cast<v4i *>(xs + wp * (32 * KS1) + ks * 32 + h * 16) = ldg4(src + ks * 32);
+        }
+    }
+    // staging roles of this thread: item -> (source of slice 0, bytes from one slice to the next, LDS offset inside a stage)
+    const char *ssrc[2];
+    int sstep[2], sdst[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int it = t + r * LB_NT;
+        ssrc[r] = nullptr, sstep[r] = 0, sdst[r] = 0;
+        if (it < 32) {
+            ssrc[r] = (const char *)p.ct1 + it * 16, sstep[r] = 512, sdst[r] = OFF_CT1 + it * 16;
+        } else if (it < 64) {
+            ssrc[r] = (const char *)p.ct2 + (it - 32) * 16, sstep[r] = 512, sdst[r] = OFF_CT2 + (it - 32) * 16;
+        } else if (it < 64 + N_W1) {
+            const int k = it - 64, row = k / (2 * KS1), chunk = k % (2 * KS1);
+            ssrc[r] = (const char *)p.w1 + (size_t)row * p.w1_pitch + chunk * 16, sstep[r] = 32 * p.w1_pitch, sdst[r] = OFF_W1 + row * (32 * KS1) + chunk * 16;
+        } else if (it < 64 + N_W1 + N_W9) {
+            const int k = it - 64 - N_W1;
+            ssrc[r] = (const char *)p.w9 + (size_t)(k >> 1) * p.w9_pitch + (k & 1) * 16, sstep[r] = 32, sdst[r] = OFF_W9 + k * 16;
+        } else if (it < N_ITEMS) {
+            const int k = it - 64 - N_W1 - N_W9;
+            ssrc[r] = (const char *)p.w3 + (size_t)(k >> 1) * p.w3_pitch + (k & 1) * 16, sstep[r] = 32, sdst[r] = OFF_W3 + k * 16;
+        }
+    }
+    v4i sreg[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (ssrc[r]) *reinterpret_cast<v4i *>(&stg[0][sdst[r]]) = ldg4(ssrc[r]);
+    if (t < 32 * CT2) ct3s[t] = ldg4(p.ct3 + t * 4);
     v16i acc2[CT2];
 #pragma unroll
     for (int c = 0; c < CT2; ++c)
@@ -103,51 +162,90 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_kernel(const LbP p) {
         for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
     // depthwise thread mapping: 4 channels cg, output column dx, output rows dy0 .. dy0 + 3
     const int cg = t & 7, dx = (t >> 3) & 15, dy0 = (t >> 7) * 4;
+    // closing: this lane's output pixel
+    const int pl = wave * 32 + l31, gy = oy0 + (pl >> 4), gx = ox0 + (pl & 15);
+    const bool out_ok = gy < p.Ho && gx < p.Wo;
+    const size_t pix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
     __syncthreads();
 
     for (int j = 0; j < p.nsl; ++j) {
-        const int par = j & 1;
-        if (j + 1 < p.nsl) {   // next slice's table rows (read two barriers from now)
-            if (t < 32) cts[par ^ 1][0][t] = ldg4(p.ct1 + ((j + 1) * 32 + t) * 4);
-            else if (t < 64) cts[par ^ 1][1][t - 32] = ldg4(p.ct2 + ((j + 1) * 32 + t - 32) * 4);
+        const char *sb = stg[j & 1];
+        const bool more = j + 1 < p.nsl;
+        if (more) {   // next slice's tables and weights: fetched now, stored to LDS between this slice's barriers
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (ssrc[r]) sreg[r] = ldg4(ssrc[r] + (size_t)(j + 1) * sstep[r]);
         }
         // ---------------------------------------------------------------- GEMM1 + quant_act1 -> hid
         {
             v4i wf[KS1];
-            const int8_t *wr = p.w1 + (size_t)(j * 32 + cperm(l31)) * p.w1_pitch + h * 16;
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) wf[ks] = ldg4(wr + ks * 32);
+            for (int ks = 0; ks < KS1; ++ks) wf[ks] = *reinterpret_cast<const v4i *>(sb + OFF_W1 + cperm(l31) * (32 * KS1) + ks * 32 + h * 16);
+            const v4i *ct1 = reinterpret_cast<const v4i *>(sb + OFF_CT1) + h * 16;
+            // passes of at most 3 accumulator tiles: OPP whole blocks + SPP shared blocks each
+            constexpr int NPASS = NOWN >= 2 ? 2 : 1, OPP = NOWN / NPASS, SPP = 2 / NPASS, NA = OPP + SPP;
+            static_assert(NOWN % NPASS == 0, "own blocks divide into the passes");
 #pragma unroll
-            for (int i = 0; i < MAXB1; ++i) {
-                const int blk = wave + 4 * i;
-                if (blk < NB1) {
-                    v16i a;
+            for (int ps = 0; ps < NPASS; ++ps) {
+                v16i a[NA];
+                int blk[NA], vbit[NA];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) a[r] = 0;
+                for (int i = 0; i < NA; ++i) {
+                    blk[i] = i < OPP ? wave + 4 * (ps * OPP + i) : NB1 - 2 + ps * SPP + (i - OPP);
+                    vbit[i] = i < OPP ? ps * OPP + i : NOWN + ps * SPP + (i - OPP);
 #pragma unroll
-                    for (int ks = 0; ks < KS1; ++ks) a = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks], xw[i][ks], a, 0, 0, 0);
-                    int pk[4];
+                    for (int r = 0; r < 16; ++r) a[i][r] = 0;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        int qv[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            qv[k] = med3i(requant<TIE>(a[4 * g + k], entry(cts[par][0][h * 16 + 4 * g + k])), p.lo1, p.hi1);
-                        pk[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const v4i xf = *reinterpret_cast<const v4i *>(xs + (blk[i] * 32 + l31) * (32 * KS1) + ks * 32 + h * 16);
+                        a[i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[ks], xf, a[i], 0, 0, 0);
                     }
-                    const bool ok = (vmask >> i) & 1;   // outside the image: the depthwise conv's zero padding
-                    const v4i w = ok ? v4i{pk[0], pk[1], pk[2], pk[3]} : v4i{0, 0, 0, 0};
-                    *reinterpret_cast<v4i *>(hid + (blk * 32 + l31) * 32 + h * 16) = w;
+                }
+                // channel-outer: a channel's constants are fetched and unpacked once for all tiles of the pass.  The accumulator
+                // tiles are only READ here (conditional in-place updates made hipcc copy them between AGPRs and VGPRs around every branch)
+                int qo[OPP][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    v4i e4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) e4[k] = ct1[4 * g + k];
+                    const bool mine = g == wave_s;   // this wave's quarter of the shared blocks (scalar condition)
+                    int qg[OPP][4], qs[SPP][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        DyNt d = entry(e4[k]);
+#pragma unroll
+                        for (int i = 0; i < OPP; ++i) qg[i][k] = med3i(requant<TIE>(a[i][4 * g + k], d), p.lo1, p.hi1);
+                        if (mine) {
+#pragma unroll
+                            for (int i = 0; i < SPP; ++i) qs[i][k] = med3i(requant<TIE>(a[OPP + i][4 * g + k], d), p.lo1, p.hi1);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < OPP; ++i) qo[i][g] = pack4_fast(qg[i][0], qg[i][1], qg[i][2], qg[i][3]);
+                    if (mine) {
+#pragma unroll
+                        for (int i = 0; i < SPP; ++i) {
+                            const int w = ((vmask >> vbit[OPP + i]) & 1) ? pack4_fast(qs[i][0], qs[i][1], qs[i][2], qs[i][3]) : 0;
+                            *reinterpret_cast<int *>(hid + (blk[OPP + i] * 32 + l31) * 32 + h * 16 + 4 * g) = w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < OPP; ++i) {
+                    const bool ok = (vmask >> vbit[i]) & 1;   // outside the image: the depthwise conv's zero padding
+                    const v4i w = ok ? v4i{qo[i][0], qo[i][1], qo[i][2], qo[i][3]} : v4i{0, 0, 0, 0};
+                    *reinterpret_cast<v4i *>(hid + (blk[i] * 32 + l31) * 32 + h * 16) = w;
                 }
             }
         }
-        __syncthreads();   // B1: hid complete
+        __syncthreads();   // B1: hid complete; every wave is past GEMM2 of the previous slice
         // ---------------------------------------------------------------- depthwise 3x3 + quant_act2 -> dwo
         {
             int wm[9][4];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
-                const int ww = *reinterpret_cast<const int *>(p.w9 + (size_t)tp * p.w9_pitch + j * 32 + cg * 4);
+                const int ww = *reinterpret_cast<const int *>(sb + OFF_W9 + tp * 32 + cg * 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) wm[tp][k] = ww & (0xff << (8 * k));
             }
@@ -175,7 +273,10 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_kernel(const LbP p) {
             }
             DyNt d[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = entry(cts[par][1][cg * 4 + k]);
+            for (int k = 0; k < 4; ++k) {
+                d[k] = entry(reinterpret_cast<const v4i *>(sb + OFF_CT2)[cg * 4 + k]);
+                asm volatile("" : "+v"(d[k].add));
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int qv[4];
@@ -184,47 +285,58 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_kernel(const LbP p) {
                 *reinterpret_cast<int *>(dwo + ((dy0 + i) * LB_TW + dx) * 32 + cg * 4) = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
             }
         }
-        __syncthreads();   // B2: dwo complete, hid free
+        if (more) {   // the other stage's last readers (GEMM2 of slice j - 1) are behind B1
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (ssrc[r]) *reinterpret_cast<v4i *>(&stg[(j & 1) ^ 1][sdst[r]]) = sreg[r];
+        }
+        __syncthreads();   // B2: dwo complete, hid free, next stage complete
         // ---------------------------------------------------------------- GEMM2 partial sum over this slice
         {
             const v4i af = *reinterpret_cast<const v4i *>(dwo + (wave * 32 + l31) * 32 + h * 16);
 #pragma unroll
             for (int c = 0; c < CT2; ++c) {
-                const v4i wf = ldg4(p.w3 + (size_t)(c * 32 + cperm(l31)) * p.w3_pitch + j * 32 + h * 16);
+                const v4i wf = *reinterpret_cast<const v4i *>(sb + OFF_W3 + (c * 32 + cperm(l31)) * 32 + h * 16);
                 acc2[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc2[c], 0, 0, 0);
             }
         }
     }
 
     // -------------------------------------------------------------------- closing: quant_act_int32 (+ identity), next QuantAct
-    const int pl = wave * 32 + l31, gy = oy0 + (pl >> 4), gx = ox0 + (pl & 15);
-    if (gy >= p.Ho || gx >= p.Wo) return;
-    const size_t pix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
-    const DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);
+    if (!out_ok) return;
+    DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);
+    asm volatile("" : "+v"(dids.add), "+v"(dq.add));
+    const int clo = p.clamp16 ? -32768 : (int)0x80000000, chi = p.clamp16 ? 32767 : 0x7fffffff;
+    auto close = [&](auto with_identity) {
 #pragma unroll
-    for (int c = 0; c < CT2; ++c) {
-        const int ch = c * 32 + h * 16;
-        if (ch >= p.out_pitch) continue;
-        const size_t elem = pix * p.out_pitch + ch;
-        int qw[4];
+        for (int c = 0; c < CT2; ++c) {
+            const int ch = c * 32 + h * 16;
+            if (ch >= p.out_pitch) continue;
+            const size_t elem = pix * p.out_pitch + ch;
+            int qw[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v4i rin = {0, 0, 0, 0};
-            if (p.res_in) rin = ldg4(p.res_in + elem + 4 * g);
-            int o[4], qv[4];
+            for (int g = 0; g < 4; ++g) {
+                int o[4], qv[4];
+                v4i rin = {0, 0, 0, 0};
+                if (decltype(with_identity)::value) rin = ldg4(p.res_in + elem + 4 * g);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int ov = requant<TIE>(acc2[c][4 * g + k], entry(ldg4(p.ct3 + (size_t)(ch + 4 * g + k) * 4)));
-                if (p.res_in) ov += requant<TIE>(rin[k], dids);
-                if (p.clamp16) ov = clampi(ov, -32768, 32767);
-                o[k] = ov;
-                qv[k] = clampi(requant<TIE>(ov, dq), p.q_lo, p.q_hi);
+                for (int k = 0; k < 4; ++k) {
+                    DyNt d = entry(ct3s[ch + 4 * g + k]);
+                    asm volatile("" : "+v"(d.add));
+                    int ov = requant<TIE>(acc2[c][4 * g + k], d);
+                    if (decltype(with_identity)::value) ov += requant<TIE>(rin[k], dids);
+                    ov = med3i(ov, clo, chi);
+                    o[k] = ov;
+                    qv[k] = med3i(requant<TIE>(ov, dq), p.q_lo, p.q_hi);
+                }
+                if (p.res_out) *reinterpret_cast<v4i *>(p.res_out + elem + 4 * g) = v4i{o[0], o[1], o[2], o[3]};
+                qw[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
             }
-            if (p.res_out) *reinterpret_cast<v4i *>(p.res_out + elem + 4 * g) = v4i{o[0], o[1], o[2], o[3]};
-            qw[g] = (int)pack4_i8(qv[0], qv[1], qv[2], qv[3]);
+            if (p.out_q) *reinterpret_cast<v4i *>(p.out_q + elem) = v4i{qw[0], qw[1], qw[2], qw[3]};
         }
-        if (p.out_q) *reinterpret_cast<v4i *>(p.out_q + elem) = v4i{qw[0], qw[1], qw[2], qw[3]};
-    }
+    };
+    if (p.res_in) close(std::true_type{});
+    else close(std::false_type{});
 }
 
 typedef void (*LbFn)(const LbP);
