@@ -63,6 +63,8 @@ SIGNATURES = {
     "hawq_conv_expand_reduce_variants": [C.POINTER(ExpandReduceArgs)],
     "hawq_linear_bottleneck": [C.POINTER(BottleneckArgs), vp],
     "hawq_linear_bottleneck_ok": [C.POINTER(BottleneckArgs)],
+    "hawq_stem3x3s2": [vp, vp, vp, i32, i32, f32, i32, i32, C.POINTER(ConvArgs), vp],
+    "hawq_stem3x3s2_ok": [vp, vp, vp, i32, i32, C.POINTER(ConvArgs)],
     "hawq_quantize_input": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp],
     "hawq_stem_conv7": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
     "hawq_stem_fused": [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32,

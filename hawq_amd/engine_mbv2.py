@@ -449,7 +449,15 @@ class MobileNetV2Engine:
         alloc = lambda n, dt: torch.empty(n + 64, dtype=dt, device=dev)[:n]
         self.x_in = x_view if x_view is not None else alloc(N * 3 * H * W, torch.float32).view(N, 3, H, W)
         init = P['init']['layer']
-        if init.im2col:
+        # the init block as ONE launch (hawq_stem3x3s2): input QuantAct + 3x3 / stride 2 conv + closing QuantActs, no patch rows in memory
+        one_stem = bool(init.im2col and P['init']['fast'] is not None and P['units'][0]['q_fast'] is not None and not self.keep_acc
+                        and init.cout_s in (16, 32) and not any(os.environ.get(k) for k in ("HAWQ_MBV2_UNFUSED", "HAWQ_MBV2_EXACT", "HAWQ_MBV2_PAD64")))
+        self._stem_args = None
+        if one_stem:
+            H0, W0 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            xq = None
+            self._u8_index, self._xq, self._u8_op = len(ops), None, None   # forward_uint8 swaps this launch for its uint8 form
+        elif init.im2col:
             # input QuantAct (quant_modules.py:271-274) straight into the init conv's 27-value patches, one 64-byte row per output pixel
             H0, W0 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
             xq = alloc(N * H0 * W0 * 64, torch.int8)
@@ -467,19 +475,22 @@ class MobileNetV2Engine:
             keep += [xq_f, xq]
 
         def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True, fast=None, id_fast=None, q_fast=None,
-                    unit=None):
+                    unit=None, stem=None):
             """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo);
             the 32-bit carrier is only written where something reads it (the next unit's identity, the pool, a tap).
             ``unit`` = dict(x, h, w, conv1 entry, conv2 entry): the whole unit as ONE launch (hawq_linear_bottleneck) - x is then the
-            unit's block input and (h, w) the depthwise conv's output grid"""
+            unit's block input and (h, w) the depthwise conv's output grid; ``stem`` = (H, W) of the images: the init block as ONE
+            launch on them (hawq_stem3x3s2), L being its im2col form"""
             ho, wo = (h + 2 * L.pad - L.kh) // L.stride + 1, (w + 2 * L.pad - L.kw) // L.stride + 1
-            a = self._conv_args(L, x if unit is None else unit['x'], n, h, w)
+            a = self._conv_args(L, (x if unit is None else unit['x']) if stem is None else self.x_in, n, h, w)
             a.epilogue, a.m, a.e = _lib.EPI_RESIDUAL, m.data_ptr(), e.data_ptr()
             out16 = None
             if need16 or self.keep_acc:
                 out16 = alloc(n * ho * wo * L.cout_s, torch.int32)
                 a.res_out, a.res_out_bits = out16.data_ptr(), 32
             in_bytes = h * w * L.cin if unit is None else unit['h'] * unit['w'] * unit['e1']['layer'].cin   # (the hidden tensors stay on chip)
+            if stem is not None:
+                in_bytes = 0   # (the images are already counted; no patch rows)
             self.plan_bytes += n * (in_bytes + ho * wo * L.cout * ((4 if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
             use_fast = (fast is not None and (res_in is None or id_fast is not None) and (nxt_q is None or q_fast is not None)
                         and not os.environ.get("HAWQ_MBV2_EXACT"))
@@ -523,6 +534,11 @@ class MobileNetV2Engine:
                 self.plan_bytes += L1.weight_bytes + L2.weight_bytes
                 self.n_fused_units += 1
                 ops.append(partial(_lib.call, "hawq_linear_bottleneck", C.byref(b), sp))
+            elif stem is not None:
+                if not use_fast or not _lib.load().hawq_stem3x3s2_ok(self.x_in.data_ptr(), None, None, stem[0], stem[1], C.byref(a)):
+                    raise RuntimeError("hawq_stem3x3s2 refuses the init block the plan selected for it")
+                self._stem_args = a
+                ops.append(partial(_lib.call, "hawq_stem3x3s2", self.x_in.data_ptr(), None, None, stem[0], stem[1], P['inv_s_in'], -128, 127, C.byref(a), sp))
             else:
                 self._convs.append((name, a))
                 ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
@@ -535,7 +551,8 @@ class MobileNetV2Engine:
         units = P['units']
         u0 = units[0]
         x16, q, h, w = closing(init, P['init']['m'], P['init']['e'], xq, N, H0, W0, None, 0, 33, True, True,
-                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block", need16=u0['residual'], fast=P['init']['fast'], q_fast=u0['q_fast'])
+                               (u0['mq'], u0['eq'], u0['q_rng']), "init_block", need16=u0['residual'], fast=P['init']['fast'], q_fast=u0['q_fast'],
+                               stem=(H, W) if one_stem else None)
         for ui, u in enumerate(units):
             name = f"unit{ui + 1}"
             x = q
@@ -715,6 +732,10 @@ class MobileNetV2Engine:
             return
         if self._u8_index is None:
             raise NotImplementedError("uint8 input needs the im2col input quantiser (3x3 / stride 2 init conv on 3 channels)")
+        if self._stem_args is not None:
+            self._u8_op = partial(_lib.call, "hawq_stem3x3s2", None, self.x_u8.data_ptr(), self.lut_dev.data_ptr(), H, W, 0.0, 0, 0,
+                                  C.byref(self._stem_args), self.stream.cuda_stream)
+            return
         self._u8_op = partial(_lib.call, "hawq_quantize_im2col3x3s2_u8", self.x_u8.data_ptr(), self.lut_dev.data_ptr(), self._xq.data_ptr(),
                               N, 3, H, W, self.stream.cuda_stream)
 

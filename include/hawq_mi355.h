@@ -313,6 +313,19 @@ int hawq_linear_bottleneck_ok(const hawq_bottleneck_args *args);
 int hawq_quantize_im2col3x3s2(const float *x, int8_t *out, int32_t N, int32_t C, int32_t H, int32_t W, float inv_scale, int32_t q_lo,
                               int32_t q_hi, void *stream);
 
+/* MobileNetV2's init block as ONE launch (round 4; q_mobilenetv2.py:176-186, 60-65 after quant_modules.py:271-274): the input QuantAct,
+ * the 3x3 / stride 2 / pad 1 conv on 3 channels, ReLU6 (as ReLU + clamp), quant_act_int32 and the first unit's block-input QuantAct;
+ * neither the patch rows of hawq_quantize_im2col3x3s2 nor anything else intermediate reaches memory.
+ *   x / x_u8: exactly one of fp32 NCHW [N][3][H][W] (then inv_scale, in_lo, in_hi describe the input QuantAct) and uint8 NHWC [N][H][W][3]
+ *             with lut int8 [3][256] (as hawq_quantize_im2col3x3s2_u8);
+ *   conv:     the 1x1 hawq_conv2d launch of the im2col path exactly as it would be issued on the patch rows (N, H = Ho, W = Wo, Cin = Cout = 64,
+ *             wgt rows = the 27 taps in (kh, kw, c) order then zeros; RESIDUAL epilogue without identity, fast_tables != 0 with ctab,
+ *             res_no_relu / res_clamp16, out_q + mq / eq / q_lo / q_hi, optional int32 res_out, out_pitch 16 or 32); `in` is ignored.
+ * hawq_stem3x3s2_ok: 1 when the launch takes this description. */
+int hawq_stem3x3s2(const float *x, const uint8_t *x_u8, const int8_t *lut, int32_t H, int32_t W, float inv_scale, int32_t in_lo, int32_t in_hi,
+                   const hawq_conv_args *conv, void *stream);
+int hawq_stem3x3s2_ok(const float *x, const uint8_t *x_u8, const int8_t *lut, int32_t H, int32_t W, const hawq_conv_args *conv);
+
 /* The same patch rows from uint8 NHWC images [N][H][W][3] (decoder output after resize / crop, quant_train.py:428-440): ToTensor +
  * Normalize + the input QuantAct as one table look-up per channel, lut int8 [3][256] built on the host with the reference
  * pipeline's own float operations (hawq_amd.quant_utils.input_quant_lut) - bit-identical to quantising the normalised fp32 tensor. */

@@ -395,7 +395,7 @@ def test_mobilenetv2_concurrent_sub_batches_are_bit_identical():
 @pytest.mark.parametrize("hw", [(224, 224), (72, 104)])
 def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, monkeypatch):
     """hawq_linear_bottleneck (one launch per unit: expand 1x1 -> depthwise 3x3 -> project 1x1 + quant_act_int32 + next QuantAct, the
-    hidden tensors never leaving the CU) against the three launches it replaces: every unit-closing tensor (int8 block input of the next
+    hidden tensors never leaving the CU) and hawq_stem3x3s2 (the init block as one launch) against the launches they replace: every unit-closing tensor (int8 block input of the next
     unit, int32 carrier where one is written) and the logits bit for bit - on the full 224 x 224 maps and on an odd geometry whose
     tiles hang over every edge (36 x 52 -> 18 x 26 -> 9 x 13 -> 5 x 7 -> 3 x 4 maps)."""
     from hawq_amd.api import build_quantized_model, calibrate
@@ -414,7 +414,8 @@ def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, monkeypat
     one = MobileNetV2Engine(model, chains=1, use_graph=False)
     y1 = one(x).clone()
     assert one.n_fused_units >= 7, one.n_fused_units   # units 1-10 of the width-1 network have <= 64-channel inputs and outputs
-    assert len(one._ops) == len(three._ops) - 2 * one.n_fused_units
+    assert one._stem_args is not None and three._stem_args is None   # the init block: hawq_stem3x3s2 against im2col + 1x1 conv
+    assert len(one._ops) == len(three._ops) - 2 * one.n_fused_units - 1
     for name in sorted(one.taps):
         if name.endswith(":next_q") or name.endswith(":out16"):
             assert np.array_equal(one.tap(name), three.tap(name)), name
