@@ -339,15 +339,241 @@ __global__ __launch_bounds__(LB_NT) LB_OCC_ATTR void linear_bottleneck_kernel(co
     else close(std::false_type{});
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second organisation ("planar", the default): the first one above keeps every tensor [pixel][channel] - natural for the MFMAs, but
+// it makes the launch VALU-bound twice over: a lane of GEMM1 owns 16 CHANNELS, so every requant needs its own table row (an LDS
+// read and two unpack instructions per output), and the depthwise conv sees 4 channels per dword, so a MAC is one v_dot4 (9 per
+// output).  Here the hidden tensor is CHANNEL-PLANAR between GEMM1 and the depthwise conv:
+//   GEMM1   operands swapped - A = block input (rows = window positions), B = W1 (columns = channels): a lane owns ONE channel and 16
+//           consecutive window positions; its requant constants are four registers for the whole slice (3-4 instructions per output)
+//           and its 16 bytes go to hidp[channel][position] as they are.  Window rows are padded to a multiple of 4 positions so that a
+//           dword never straddles two rows; positions outside the image are cleared through a byte mask map built with the window.
+//   DW      thread = (channel, output row): a dword holds 4 horizontally adjacent positions of its channel, so one v_dot4 covers a
+//           whole tap row of an output when the three taps share a dword and two when they straddle: 4.5 per output instead of 9, the
+//           six shifted copies of the weight row are built once per slice.  Results go to dwo[pixel][channel] byte by byte - the
+//           one transposition of the unit, GEMM2 wants K = channels contiguous.
+//   GEMM2 / closing as above.
+template <int S, int KS1, int CT2, bool TIE>
+__global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const LbP p) {
+    constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WWP = (WW + 3) / 4 * 4, NPOS = WH * WWP, NB1 = (NPOS + 31) / 32;
+    constexpr int MAXB = (NB1 + 3) / 4;
+    constexpr int CHP = NB1 * 32 + 4;   // bytes per channel plane: an odd number of dwords (conflict-free dword accesses across channels)
+    static_assert((CHP / 4) % 2 == 1, "plane pitch");
+    constexpr int DWP = LB_TW * 32 + 32;   // bytes per output row of dwo: odd and even rows fall on different banks
+    constexpr int N_W1 = 64 * KS1, N_W9 = 18, N_W3 = 64 * CT2, N_ITEMS = 64 + N_W1 + N_W9 + N_W3;   // 16-byte items per slice
+    constexpr int OFF_CT1 = 0, OFF_CT2 = 512, OFF_W1 = 1024, OFF_W9 = OFF_W1 + 1024 * KS1, OFF_W3 = OFF_W9 + 288, BUF = OFF_W3 + 1024 * CT2;
+    static_assert(N_ITEMS <= 2 * LB_NT, "two items per thread");
+    __shared__ __attribute__((aligned(16))) char xs[NB1 * 32 * 32 * KS1];   // block input [window position][K]
+    __shared__ __attribute__((aligned(16))) char vm[NB1 * 32];              // 0xff inside the image, 0 outside (and on padding positions)
+    __shared__ __attribute__((aligned(16))) char hidp[32 * CHP];            // quant_act1 output [channel of the slice][window position]
+    __shared__ __attribute__((aligned(16))) char dwo[LB_TH * DWP];          // quant_act2 output [output pixel][channel of the slice]
+    __shared__ __attribute__((aligned(16))) char stg[2][BUF];
+    __shared__ v4i ct3s[32 * CT2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y, n = bid / p.tiles_y;
+    const int oy0 = ty * LB_TH, ox0 = tx * LB_TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int8_t *img = p.x + (size_t)n * p.H * p.W * p.in_pitch;
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wave + 4 * i, pos = blk * 32 + l31;
+        if (blk < NB1) {
+            const int wy = pos / WWP, wx = pos - wy * WWP, iy = iy0 + wy, ix = ix0 + wx;
+            const bool ok = wy < WH && wx < WW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int8_t *src = img + (size_t)(ok ? iy * p.W + ix : 0) * p.in_pitch + h * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) *reinterpret_cast<v4i *>(xs + pos * (32 * KS1) + ks * 32 + h * 16) = ldg4(src + ks * 32);
+            if (h == 0) vm[pos] = ok ? (char)0xff : (char)0;
+        }
+    }
+    const char *ssrc[2];
+    int sstep[2], sdst[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int it = t + r * LB_NT;
+        ssrc[r] = nullptr, sstep[r] = 0, sdst[r] = 0;
+        if (it < 32) {
+            ssrc[r] = (const char *)p.ct1 + it * 16, sstep[r] = 512, sdst[r] = OFF_CT1 + it * 16;
+        } else if (it < 64) {
+            ssrc[r] = (const char *)p.ct2 + (it - 32) * 16, sstep[r] = 512, sdst[r] = OFF_CT2 + (it - 32) * 16;
+        } else if (it < 64 + N_W1) {
+            const int k = it - 64, row = k / (2 * KS1), chunk = k % (2 * KS1);
+            ssrc[r] = (const char *)p.w1 + (size_t)row * p.w1_pitch + chunk * 16, sstep[r] = 32 * p.w1_pitch, sdst[r] = OFF_W1 + row * (32 * KS1) + chunk * 16;
+        } else if (it < 64 + N_W1 + N_W9) {
+            const int k = it - 64 - N_W1;
+            ssrc[r] = (const char *)p.w9 + (size_t)(k >> 1) * p.w9_pitch + (k & 1) * 16, sstep[r] = 32, sdst[r] = OFF_W9 + k * 16;
+        } else if (it < N_ITEMS) {
+            const int k = it - 64 - N_W1 - N_W9;
+            ssrc[r] = (const char *)p.w3 + (size_t)(k >> 1) * p.w3_pitch + (k & 1) * 16, sstep[r] = 32, sdst[r] = OFF_W3 + k * 16;
+        }
+    }
+    v4i sreg[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (ssrc[r]) *reinterpret_cast<v4i *>(&stg[0][sdst[r]]) = ldg4(ssrc[r]);
+    if (t < 32 * CT2) ct3s[t] = ldg4(p.ct3 + t * 4);
+    v16i acc2[CT2];
+#pragma unroll
+    for (int c = 0; c < CT2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
+    const int dc = t & 31, doy = t >> 5;   // depthwise: this thread's channel (== l31) and output row
+    const int pl = wave * 32 + l31, gy = oy0 + (pl >> 4), gx = ox0 + (pl & 15);
+    const bool out_ok = gy < p.Ho && gx < p.Wo;
+    const size_t pix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
+    __syncthreads();
+
+    for (int j = 0; j < p.nsl; ++j) {
+        const char *sb = stg[j & 1];
+        const bool more = j + 1 < p.nsl;
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (ssrc[r]) sreg[r] = ldg4(ssrc[r] + (size_t)(j + 1) * sstep[r]);
+        }
+        // ---------------------------------------------------------------- GEMM1 + quant_act1 -> hidp (this lane: channel l31)
+        {
+            v4i wf[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) wf[ks] = *reinterpret_cast<const v4i *>(sb + OFF_W1 + l31 * (32 * KS1) + ks * 32 + h * 16);
+            DyNt d1 = entry(reinterpret_cast<const v4i *>(sb + OFF_CT1)[l31]);
+            asm volatile("" : "+v"(d1.add));
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int blk = wave + 4 * i;
+                if (blk < NB1) {
+                    v16i a;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = 0;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        const v4i xf = *reinterpret_cast<const v4i *>(xs + (blk * 32 + cperm(l31)) * (32 * KS1) + ks * 32 + h * 16);
+                        a = __builtin_amdgcn_mfma_i32_32x32x32_i8(xf, wf[ks], a, 0, 0, 0);
+                    }
+                    const v4i m4 = *reinterpret_cast<const v4i *>(vm + blk * 32 + 16 * h);
+                    char *dst = hidp + l31 * CHP + blk * 32 + 16 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int qv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) qv[k] = med3i(requant<TIE>(a[4 * g + k], d1), p.lo1, p.hi1);
+                        *reinterpret_cast<int *>(dst + 4 * g) = pack4_fast(qv[0], qv[1], qv[2], qv[3]) & m4[g];
+                    }
+                }
+            }
+        }
+        __syncthreads();   // B1: hidp complete; every wave is past GEMM2 of the previous slice
+        // ---------------------------------------------------------------- depthwise 3x3 + quant_act2 -> dwo (this thread: channel dc, row doy)
+        {
+            int acc[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[x] = 0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned char *wp = reinterpret_cast<const unsigned char *>(sb + OFF_W9 + kh * 96 + dc);
+                const unsigned wa = (unsigned)wp[0] | ((unsigned)wp[32] << 8) | ((unsigned)wp[64] << 16);   // taps kw = 0, 1, 2 in bytes 0, 1, 2
+                const int *rowp = reinterpret_cast<const int *>(hidp + dc * CHP + (doy * S + kh) * WWP);
+                if constexpr (S == 1) {
+                    // output x = 4 q + r reads bytes x .. x + 2 of the row: inside dword q for r = 0, 1; across q and q + 1 for r = 2, 3
+                    const int w0 = (int)wa, w1 = (int)(wa << 8), w2a = (int)(wa << 16), w2b = (int)(wa >> 16), w3a = (int)(wa << 24), w3b = (int)(wa >> 8);
+                    int r[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) r[q] = rowp[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[4 * q] = __builtin_amdgcn_sdot4(r[q], w0, acc[4 * q], false);
+                        acc[4 * q + 1] = __builtin_amdgcn_sdot4(r[q], w1, acc[4 * q + 1], false);
+                        acc[4 * q + 2] = __builtin_amdgcn_sdot4(r[q], w2a, acc[4 * q + 2], false);
+                        acc[4 * q + 2] = __builtin_amdgcn_sdot4(r[q + 1], w2b, acc[4 * q + 2], false);
+                        acc[4 * q + 3] = __builtin_amdgcn_sdot4(r[q], w3a, acc[4 * q + 3], false);
+                        acc[4 * q + 3] = __builtin_amdgcn_sdot4(r[q + 1], w3b, acc[4 * q + 3], false);
+                    }
+                } else {
+                    // output x reads bytes 2 x .. 2 x + 2: inside dword x / 2 for even x; across x / 2 and x / 2 + 1 for odd x
+                    const int w0 = (int)wa, w1a = (int)(wa << 16), w1b = (int)(wa >> 16);
+                    int r[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) r[q] = rowp[q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        acc[2 * q] = __builtin_amdgcn_sdot4(r[q], w0, acc[2 * q], false);
+                        acc[2 * q + 1] = __builtin_amdgcn_sdot4(r[q], w1a, acc[2 * q + 1], false);
+                        acc[2 * q + 1] = __builtin_amdgcn_sdot4(r[q + 1], w1b, acc[2 * q + 1], false);
+                    }
+                }
+            }
+            DyNt d2 = entry(reinterpret_cast<const v4i *>(sb + OFF_CT2)[dc]);
+            asm volatile("" : "+v"(d2.add));
+            char *dst = dwo + doy * DWP + dc;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) dst[x * 32] = (char)med3i(requant<TIE>(acc[x], d2), p.lo2, p.hi2);
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (ssrc[r]) *reinterpret_cast<v4i *>(&stg[(j & 1) ^ 1][sdst[r]]) = sreg[r];
+        }
+        __syncthreads();   // B2: dwo complete, hidp free, next stage complete
+        // ---------------------------------------------------------------- GEMM2 partial sum over this slice
+        {
+            const v4i af = *reinterpret_cast<const v4i *>(dwo + (pl >> 4) * DWP + (pl & 15) * 32 + h * 16);
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) {
+                const v4i wf = *reinterpret_cast<const v4i *>(sb + OFF_W3 + (c * 32 + cperm(l31)) * 32 + h * 16);
+                acc2[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc2[c], 0, 0, 0);
+            }
+        }
+    }
+
+    // -------------------------------------------------------------------- closing: quant_act_int32 (+ identity), next QuantAct
+    if (!out_ok) return;
+    DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);
+    asm volatile("" : "+v"(dids.add), "+v"(dq.add));
+    const int clo = p.clamp16 ? -32768 : (int)0x80000000, chi = p.clamp16 ? 32767 : 0x7fffffff;
+    auto close = [&](auto with_identity) {
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            const int ch = c * 32 + h * 16;
+            if (ch >= p.out_pitch) continue;
+            const size_t elem = pix * p.out_pitch + ch;
+            int qw[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int o[4], qv[4];
+                v4i rin = {0, 0, 0, 0};
+                if (decltype(with_identity)::value) rin = ldg4(p.res_in + elem + 4 * g);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    DyNt d = entry(ct3s[ch + 4 * g + k]);
+                    asm volatile("" : "+v"(d.add));
+                    int ov = requant<TIE>(acc2[c][4 * g + k], d);
+                    if (decltype(with_identity)::value) ov += requant<TIE>(rin[k], dids);
+                    ov = med3i(ov, clo, chi);
+                    o[k] = ov;
+                    qv[k] = med3i(requant<TIE>(ov, dq), p.q_lo, p.q_hi);
+                }
+                if (p.res_out) *reinterpret_cast<v4i *>(p.res_out + elem + 4 * g) = v4i{o[0], o[1], o[2], o[3]};
+                qw[g] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+            }
+            if (p.out_q) *reinterpret_cast<v4i *>(p.out_q + elem) = v4i{qw[0], qw[1], qw[2], qw[3]};
+        }
+    };
+    if (p.res_in) close(std::true_type{});
+    else close(std::false_type{});
+}
+
 typedef void (*LbFn)(const LbP);
 template <int S, int KS1, int CT2>
-LbFn pick_tie(bool tie) {
+LbFn pick_tie(bool tie, bool planar) {
+    if (planar) return tie ? linear_bottleneck_planar_kernel<S, KS1, CT2, true> : linear_bottleneck_planar_kernel<S, KS1, CT2, false>;
     return tie ? linear_bottleneck_kernel<S, KS1, CT2, true> : linear_bottleneck_kernel<S, KS1, CT2, false>;
 }
 template <int S>
-LbFn pick(int ks1, int ct2, bool tie) {
-    if (ks1 == 1) return ct2 == 1 ? pick_tie<S, 1, 1>(tie) : pick_tie<S, 1, 2>(tie);
-    return ct2 == 1 ? pick_tie<S, 2, 1>(tie) : pick_tie<S, 2, 2>(tie);
+LbFn pick(int ks1, int ct2, bool tie, bool planar) {
+    if (ks1 == 1) return ct2 == 1 ? pick_tie<S, 1, 1>(tie, planar) : pick_tie<S, 1, 2>(tie, planar);
+    return ct2 == 1 ? pick_tie<S, 2, 1>(tie, planar) : pick_tie<S, 2, 2>(tie, planar);
 }
 
 bool e_fast(int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; }
@@ -372,6 +598,7 @@ const char *lb_refusal(const hawq_bottleneck_args *a) {
     if (!q.out_q && !q.res_out) return "nothing to write";
     const int H = e.H, W = e.W, Ho = (H - 1) / a->dw_stride + 1, Wo = (W - 1) / a->dw_stride + 1;
     if (q.N != e.N || q.H != Ho || q.W != Wo) return "project geometry must be the depthwise conv's output grid";
+    if (a->tile < 0 || a->tile > 2) return "tile: 0 (default), 1 or 2";
     if ((long long)e.N * ((Ho + LB_TH - 1) / LB_TH) * ((Wo + LB_TW - 1) / LB_TW) > 0x7fffffffll) return "grid too large";
     return nullptr;
 }
@@ -400,7 +627,8 @@ extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *strea
     p.tiles_x = (p.Wo + LB_TW - 1) / LB_TW, p.tiles_y = (p.Ho + LB_TH - 1) / LB_TH;
     const bool tie = ((e.fast_tables | a->dw_fast_tables | q.fast_tables) & 4) != 0;
     const int ks1 = p.in_pitch <= 32 ? 1 : 2, ct2 = p.out_pitch <= 32 ? 1 : 2;
-    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie) : pick<2>(ks1, ct2, tie);
+    const bool planar = a->tile != 1;   // tile 1: the [pixel][channel] organisation (A/B measurements); 0 / 2: the planar one
+    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar) : pick<2>(ks1, ct2, tie, planar);
     hipLaunchKernelGGL(fn, dim3(p.N * p.tiles_y * p.tiles_x), dim3(LB_NT), 0, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;

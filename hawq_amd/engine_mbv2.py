@@ -528,6 +528,7 @@ class MobileNetV2Engine:
                 C.memmove(C.byref(b.project), C.byref(a), C.sizeof(a))
                 b.dw_wgt9c, b.dw_ctab = L2.w9p.data_ptr(), e2['dw_ctab'].data_ptr()
                 b.dw_stride, b.dw_q_lo, b.dw_q_hi, b.dw_fast_tables, b.c_mid = L2.stride, e2['lo'], e2['hi'], e2['dw_fast'], L2.cout
+                b.tile = int(os.environ.get("HAWQ_MBV2_UNIT_TILE", 0))   # 1: the [pixel][channel] organisation of the launch (A/B switch)
                 if not _lib.load().hawq_linear_bottleneck_ok(C.byref(b)):
                     raise RuntimeError("hawq_linear_bottleneck refuses a unit the plan selected for it")
                 keep.append(b)

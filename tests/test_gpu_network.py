@@ -391,9 +391,10 @@ def test_mobilenetv2_concurrent_sub_batches_are_bit_identical():
             assert len(eng.subs) == 2 and [s._batch[0] for s in eng.subs] == [11, 10]
 
 
+@pytest.mark.parametrize("organisation", ["planar", "pixel_major"])
 @pytest.mark.parametrize("scheme", ["uniform8", "bops_0.5"])
 @pytest.mark.parametrize("hw", [(224, 224), (72, 104)])
-def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, monkeypatch):
+def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, organisation, monkeypatch):
     """hawq_linear_bottleneck (one launch per unit: expand 1x1 -> depthwise 3x3 -> project 1x1 + quant_act_int32 + next QuantAct, the
     hidden tensors never leaving the CU) and hawq_stem3x3s2 (the init block as one launch) against the launches they replace: every unit-closing tensor (int8 block input of the next
     unit, int32 carrier where one is written) and the logits bit for bit - on the full 224 x 224 maps and on an odd geometry whose
@@ -411,6 +412,8 @@ def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, monkeypat
     y3 = three(x).clone()
     assert three.n_fused_units == 0
     monkeypatch.delenv("HAWQ_MBV2_UNFUSED")
+    if organisation == "pixel_major":   # the launch's first organisation (hawq_bottleneck_args.tile = 1)
+        monkeypatch.setenv("HAWQ_MBV2_UNIT_TILE", "1")
     one = MobileNetV2Engine(model, chains=1, use_graph=False)
     y1 = one(x).clone()
     assert one.n_fused_units >= 7, one.n_fused_units   # units 1-10 of the width-1 network have <= 64-channel inputs and outputs
