@@ -353,7 +353,13 @@ __global__ __launch_bounds__(LB_NT) LB_OCC_ATTR void linear_bottleneck_kernel(co
 //           six shifted copies of the weight row are built once per slice.  Results go to dwo[pixel][channel] byte by byte - the
 //           one transposition of the unit, GEMM2 wants K = channels contiguous.
 //   GEMM2 / closing as above.
-template <int S, int KS1, int CT2, bool TIE>
+// K0H: no per-channel pre-shift on the hidden side (conv1 and depthwise tables, fast_tables bit 3 of both): one instruction less per requant
+template <bool TIE, bool K0>
+__device__ __forceinline__ int requant_h(int v, const DyNt &d) {
+    return TIE ? dyadic_tie(v, d) : dyadic_nt_k<K0>(v, d);
+}
+
+template <int S, int KS1, int CT2, bool TIE, bool K0H>
 __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const LbP p) {
     constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WWP = (WW + 3) / 4 * 4, NPOS = WH * WWP, NB1 = (NPOS + 31) / 32;
     constexpr int MAXB = (NB1 + 3) / 4;
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
                     for (int g = 0; g < 4; ++g) {
                         int qv[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) qv[k] = med3i(requant<TIE>(a[4 * g + k], d1), p.lo1, p.hi1);
+                        for (int k = 0; k < 4; ++k) qv[k] = med3i(requant_h<TIE, K0H>(a[4 * g + k], d1), p.lo1, p.hi1);
                         *reinterpret_cast<int *>(dst + 4 * g) = pack4_fast(qv[0], qv[1], qv[2], qv[3]) & m4[g];
                     }
                 }
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
             asm volatile("" : "+v"(d2.add));
             char *dst = dwo + doy * DWP + dc;
 #pragma unroll
-            for (int x = 0; x < 16; ++x) dst[x * 32] = (char)med3i(requant<TIE>(acc[x], d2), p.lo2, p.hi2);
+            for (int x = 0; x < 16; ++x) dst[x * 32] = (char)med3i(requant_h<TIE, K0H>(acc[x], d2), p.lo2, p.hi2);
         }
         if (more) {
 #pragma unroll
@@ -565,15 +571,22 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
 }
 
 typedef void (*LbFn)(const LbP);
+// organisation 1 ([pixel][channel]) exists for K steps / output blocks up to 2; the planar one up to 3 (96-channel inputs and outputs)
 template <int S, int KS1, int CT2>
-LbFn pick_tie(bool tie, bool planar) {
-    if (planar) return tie ? linear_bottleneck_planar_kernel<S, KS1, CT2, true> : linear_bottleneck_planar_kernel<S, KS1, CT2, false>;
-    return tie ? linear_bottleneck_kernel<S, KS1, CT2, true> : linear_bottleneck_kernel<S, KS1, CT2, false>;
+LbFn pick_variant(bool tie, bool planar, bool k0h) {
+    if constexpr (KS1 <= 2 && CT2 <= 2) {
+        if (!planar) return tie ? linear_bottleneck_kernel<S, KS1, CT2, true> : linear_bottleneck_kernel<S, KS1, CT2, false>;
+    }
+    if (k0h && !tie) return linear_bottleneck_planar_kernel<S, KS1, CT2, false, true>;
+    return tie ? linear_bottleneck_planar_kernel<S, KS1, CT2, true, false> : linear_bottleneck_planar_kernel<S, KS1, CT2, false, false>;
+}
+template <int S, int KS1>
+LbFn pick_ct2(int ct2, bool tie, bool planar, bool k0h) {
+    return ct2 == 1 ? pick_variant<S, KS1, 1>(tie, planar, k0h) : ct2 == 2 ? pick_variant<S, KS1, 2>(tie, planar, k0h) : pick_variant<S, KS1, 3>(tie, planar, k0h);
 }
 template <int S>
-LbFn pick(int ks1, int ct2, bool tie, bool planar) {
-    if (ks1 == 1) return ct2 == 1 ? pick_tie<S, 1, 1>(tie, planar) : pick_tie<S, 1, 2>(tie, planar);
-    return ct2 == 1 ? pick_tie<S, 2, 1>(tie, planar) : pick_tie<S, 2, 2>(tie, planar);
+LbFn pick(int ks1, int ct2, bool tie, bool planar, bool k0h) {
+    return ks1 == 1 ? pick_ct2<S, 1>(ct2, tie, planar, k0h) : ks1 == 2 ? pick_ct2<S, 2>(ct2, tie, planar, k0h) : pick_ct2<S, 3>(ct2, tie, planar, k0h);
 }
 
 bool e_fast(int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; }
@@ -588,9 +601,11 @@ const char *lb_refusal(const hawq_bottleneck_args *a) {
     if (e.epilogue != HAWQ_EPI_REQUANT || !e.fast_tables || !e.relu) return "expand: REQUANT epilogue with ReLU and fast_tables";
     if (q.epilogue != HAWQ_EPI_RESIDUAL || !q.fast_tables || !q.res_no_relu) return "project: signed RESIDUAL epilogue (res_no_relu) with fast_tables";
     if (!a->dw_fast_tables || (a->dw_stride != 1 && a->dw_stride != 2)) return "depthwise: fast tables, stride 1 or 2";
-    if (e.Cin != 64 || (e.in_pitch != 0 && e.in_pitch != 16 && e.in_pitch != 32 && e.in_pitch != 64)) return "expand: K = 64 packed weights, in_pitch 16 / 32 / 64";
+    const int ip = e.in_pitch ? e.in_pitch : e.Cin, op = q.out_pitch ? q.out_pitch : q.Cout;
+    if ((e.Cin != 64 && e.Cin != 128) || (ip != 16 && ip != 32 && ip != 64 && ip != 96) || ip > e.Cin) return "expand: K = 64 / 128 packed weights, in_pitch 16 / 32 / 64 / 96";
     if (e.Cout <= 0 || e.Cout % 64 || q.Cin != e.Cout || a->c_mid <= 0 || a->c_mid > e.Cout) return "hidden width: expand.Cout == project.Cin, a multiple of 64, c_mid inside it";
-    if (q.Cout != 64 || (q.out_pitch != 0 && q.out_pitch != 16 && q.out_pitch != 32 && q.out_pitch != 64)) return "project: Cout = 64 packed rows, out_pitch 16 / 32 / 64";
+    if ((q.Cout != 64 && q.Cout != 128) || (op != 16 && op != 32 && op != 64 && op != 96) || op > q.Cout) return "project: Cout = 64 / 128 packed rows, out_pitch 16 / 32 / 64 / 96";
+    if (a->tile == 1 && (ip > 64 || op > 64)) return "tile 1 (the [pixel][channel] organisation) takes at most 64-channel inputs and outputs";
     if (e.q_hi < 0 || e.q_hi > 127 || a->dw_q_lo < 0 || a->dw_q_hi < a->dw_q_lo || a->dw_q_hi > 127) return "hidden activations must be 0 .. 127 int8 (ReLU in the clamp)";
     if (q.out_q && (q.out_bits != 8 || q.q_lo < -128 || q.q_hi > 127 || q.q_lo > q.q_hi || q.mq < 0 || !e_fast(q.eq))) return "project: int8 out_q with a fast (mq, eq)";
     if (q.res_in && (q.res_in_bits != 32 || q.m_id_scalar < 0 || !e_fast(q.e_id_scalar) || a->dw_stride != 1)) return "identity: int32 carrier, fast scalar table, stride 1";
@@ -615,7 +630,7 @@ extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *strea
     LbP p;
     p.x = (const int8_t *)e.in;
     p.N = e.N, p.H = e.H, p.W = e.W, p.Ho = q.H, p.Wo = q.W;
-    p.in_pitch = e.in_pitch ? e.in_pitch : 64;
+    p.in_pitch = e.in_pitch ? e.in_pitch : e.Cin;
     p.w1 = (const int8_t *)e.wgt, p.w1_pitch = e.Cin, p.ct1 = e.ctab, p.lo1 = e.q_lo < 0 ? 0 : e.q_lo, p.hi1 = e.q_hi;
     p.w9 = a->dw_wgt9c, p.w9_pitch = e.Cout, p.ct2 = a->dw_ctab, p.lo2 = a->dw_q_lo, p.hi2 = a->dw_q_hi;
     p.w3 = (const int8_t *)q.wgt, p.w3_pitch = q.Cin, p.ct3 = q.ctab;
@@ -623,12 +638,13 @@ extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *strea
     p.res_in = (const int32_t *)q.res_in, p.m_id = q.res_in ? q.m_id_scalar : 0, p.e_id = q.res_in ? q.e_id_scalar : 33;
     p.res_out = (int32_t *)q.res_out, p.out_q = (int8_t *)q.out_q;
     p.mq = q.out_q ? q.mq : 0, p.eq = q.out_q ? q.eq : 33, p.q_lo = q.q_lo, p.q_hi = q.q_hi, p.clamp16 = q.res_clamp16;
-    p.out_pitch = q.out_pitch ? q.out_pitch : 64;
+    p.out_pitch = q.out_pitch ? q.out_pitch : q.Cout;
     p.tiles_x = (p.Wo + LB_TW - 1) / LB_TW, p.tiles_y = (p.Ho + LB_TH - 1) / LB_TH;
     const bool tie = ((e.fast_tables | a->dw_fast_tables | q.fast_tables) & 4) != 0;
-    const int ks1 = p.in_pitch <= 32 ? 1 : 2, ct2 = p.out_pitch <= 32 ? 1 : 2;
+    const int ks1 = (p.in_pitch + 31) / 32, ct2 = (p.out_pitch + 31) / 32;
     const bool planar = a->tile != 1;   // tile 1: the [pixel][channel] organisation (A/B measurements); 0 / 2: the planar one
-    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar) : pick<2>(ks1, ct2, tie, planar);
+    const bool k0h = (e.fast_tables & 8) && (a->dw_fast_tables & 8);   // the caller's promise: no per-channel pre-shift in ctab / dw_ctab
+    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar, k0h) : pick<2>(ks1, ct2, tie, planar, k0h);
     hipLaunchKernelGGL(fn, dim3(p.N * p.tiles_y * p.tiles_x), dim3(LB_NT), 0, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;

@@ -247,7 +247,7 @@ class MobileNetV2Engine:
                     cp = layer.cout_p
                     ent['ctab'] = _i32(packing.pack_ctab(_padded(layer.b_host, cp), _padded(mm, cp), _padded(ee, cp, 33)), dev)
                     ent['m'], ent['e'] = _i32(_padded(mm, cp), dev), _i32(_padded(ee, cp, 33), dev)
-                    ent['fast'] = 1 if tables_are_fast(mm, ee, layer.vbits) else 5
+                    ent['fast'] = (1 if tables_are_fast(mm, ee, layer.vbits) else 5) | (8 if not (np.asarray(ee) >> 8).any() else 0)   # bit 3: no pre-shifts
             else:
                 # depthwise: the same contract for the one-launch unit (hawq_linear_bottleneck); hawq_depthwise3x3_requant keeps (m, e)
                 try:
@@ -258,7 +258,7 @@ class MobileNetV2Engine:
                 if fits:
                     cp = layer.cout_p
                     ent['dw_ctab'] = _i32(packing.pack_ctab(_padded(layer.b_host, cp), _padded(mm, cp), _padded(ee, cp, 33)), dev)
-                    ent['dw_fast'] = 1 if tables_are_fast(mm, ee, layer.vbits) else 5
+                    ent['dw_fast'] = (1 if tables_are_fast(mm, ee, layer.vbits) else 5) | (8 if not (np.asarray(ee) >> 8).any() else 0)
             return ent
 
         # init block: conv -> ReLU6 -> quant_act_int32 (16 bit)
@@ -348,7 +348,7 @@ class MobileNetV2Engine:
 
     def _one_launch(self, u, nq_fast) -> bool:
         """Does this unit run as one hawq_linear_bottleneck launch?  Needs: conv1 1x1 + depthwise 3x3 + conv3 1x1 with every requant
-        table proved for the fast contract, block input and output at most 64 channels wide (the launch keeps the projection's
+        table proved for the fast contract, block input and output at most 96 channels wide (the launch keeps the projection's
         accumulators of an 8 x 16 pixel tile in registers).  HAWQ_MBV2_UNFUSED=1: three launches per unit everywhere (A/B switch);
         tapped plans (keep_accumulators) always run the three launches - the taps ARE the intermediate tensors."""
         if self.keep_acc or os.environ.get("HAWQ_MBV2_UNFUSED") or os.environ.get("HAWQ_MBV2_EXACT") or os.environ.get("HAWQ_MBV2_PAD64"):
@@ -363,7 +363,8 @@ class MobileNetV2Engine:
             return False
         if u['residual'] and u.get('id_fast') is None:
             return False
-        return L1.cin_p == 64 and L3.cout_p == 64 and L1.cin_s in (16, 32, 64) and L3.cout_s in (16, 32, 64) and e1['hi'] <= 127 and e2['hi'] <= 127
+        wide = (16, 32, 64) if os.environ.get("HAWQ_MBV2_UNIT_TILE") == "1" else (16, 32, 64, 96)
+        return L1.cin_p in (64, 128) and L3.cout_p in (64, 128) and L1.cin_s in wide and L3.cout_s in wide and e1['hi'] <= 127 and e2['hi'] <= 127
 
     def _tap(self, ops, keep, name, a, N, ho, wo, cout, cout_p):
         """extra RAW launch exposing the conv's int32 accumulators (tests only)"""

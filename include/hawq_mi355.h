@@ -285,13 +285,16 @@ int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32
  * 1x1 expand conv on the tile's halo window, runs the depthwise taps out of LDS and feeds the projection GEMM from LDS, 32 hidden
  * channels at a time.  Same integers as the three launches (hawq_conv2d REQUANT, hawq_depthwise3x3_requant, hawq_conv2d RESIDUAL).
  *   expand:  as for hawq_conv2d with the REQUANT epilogue and fast_tables != 0 (ctab, q_lo / q_hi, relu = 1); 1x1 / stride 1; Cin is the
- *            K of its packed weights (64), in_pitch in {16, 32} or dense 64; Cout = the hidden width padded to 64; out_q is ignored.
+ *            K of its packed weights (64 or 128), in_pitch in {16, 32, 64, 96} (0 = Cin); Cout = the hidden width padded to 64; out_q is
+ *            ignored.  fast_tables bit 3 on BOTH expand and dw_fast_tables (no per-channel pre-shift in ctab / dw_ctab) selects the
+ *            instantiation without the shift.
  *   dw_*:    wgt9c [9][expand.Cout] int8 tap-major (zero beyond the real channels); dw_ctab [expand.Cout][4] fused constants of its
  *            requant with the bias folded in (hawq_amd.packing.pack_ctab); dw_fast_tables as hawq_conv_args.fast_tables (1, or 5 = exact
  *            ties); clamp [dw_q_lo >= 0 (ReLU), dw_q_hi <= 127].
  *   project: as for hawq_conv2d with the RESIDUAL epilogue on the direct form: fast_tables != 0 (ctab), res_no_relu = 1, res_clamp16,
  *            res_in (int32, optional identity: then H x W, stride 1, out_pitch == expand's in_pitch), res_out (int32, optional), out_q
- *            int8 (optional), mq / eq / q_lo / q_hi; Cin == expand.Cout; out_pitch in {16, 32} or dense 64 (Cout = 64); `in` is ignored.
+ *            int8 (optional), mq / eq / q_lo / q_hi; Cin == expand.Cout; Cout = 64 or 128 packed rows, out_pitch in {16, 32, 64, 96}
+ *            (0 = Cout); `in` is ignored.
  *   c_mid:   real hidden channels (channels >= c_mid of every hidden-side table / weight are zero padding).
  * hawq_linear_bottleneck_ok: 1 when this launch takes the unit as described, else 0 (use the three launches). */
 typedef struct hawq_bottleneck_args {
@@ -301,7 +304,7 @@ typedef struct hawq_bottleneck_args {
     const int32_t *dw_ctab;
     int32_t dw_stride, dw_q_lo, dw_q_hi, dw_fast_tables;
     int32_t c_mid;
-    int32_t tile;   /* 0 = default; reserved for variants */
+    int32_t tile;   /* 0 = default (channel-planar hidden tensor); 1 = the [pixel][channel] organisation (inputs / outputs up to 64 channels) */
 } hawq_bottleneck_args;
 int hawq_linear_bottleneck(const hawq_bottleneck_args *args, void *stream);
 int hawq_linear_bottleneck_ok(const hawq_bottleneck_args *args);

@@ -40,6 +40,13 @@ with torch.cuda.stream(eng.stream):
             _, _x, _w, _b, _m, _e, n, h, w, c, cv, s = op.args[:12]
             extra = f"N={n} {h}x{w} C={c} (valid {cv}) stride={s}"
         rows.append((i, name, us, extra))
+if "--preshift" in sys.argv:   # how many per-channel requant tables of each unit carry a pre-shift k > 0 (conv1 / depthwise / conv3)
+    for ui, u in enumerate(eng.P['units']):
+        def nk(t):
+            return "-" if t is None else int(((t.view(-1, 4)[:, 1] >> 8) > 0).sum().item())
+        e1, e2 = u['layers'][0], u['layers'][1]
+        print(f"unit {ui + 1}: k > 0 in conv1 {nk(e1.get('ctab'))}, depthwise {nk(e2.get('dw_ctab'))}, conv3 {nk(u['proj']['fast']['ctab'] if u['proj']['fast'] else None)}; "
+              f"scalars q_fast {u['q_fast']}, id_fast {u.get('id_fast')}")
 for i, name, us, extra in rows:
     print(f"{i:3d} {name:28s} {us:7.1f} us  {extra}")
 print(f"sum of launches {total:.1f} us for batch {N} (one chain); {eng.n_fused_units} one-launch units; tiles {eng.tile_choice}")
