@@ -359,10 +359,13 @@ __device__ __forceinline__ int requant_h(int v, const DyNt &d) {
     return TIE ? dyadic_tie(v, d) : dyadic_nt_k<K0>(v, d);
 }
 
-template <int S, int KS1, int CT2, bool TIE, bool K0H>
-__global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const LbP p) {
+// NG: slice groups.  Maps with few tiles (14 x 14 at batch 128: one workgroup per CU) leave one wave per SIMD and every latency of the
+// per-slice chain exposed; with NG > 1 the workgroup has NG x 4 waves, group g walks slices g, g + NG, .. with its own hidp / dwo /
+// stage buffers (the block-input window is shared) and the groups' projection accumulators are summed through LDS at the end.
+template <int S, int KS1, int CT2, bool TIE, bool K0H, int NG>
+__global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(const LbP p) {
     constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WWP = (WW + 3) / 4 * 4, NPOS = WH * WWP, NB1 = (NPOS + 31) / 32;
-    constexpr int MAXB = (NB1 + 3) / 4;
+    constexpr int MAXB = (NB1 + 3) / 4, MAXBP = (NB1 + 4 * NG - 1) / (4 * NG);
     constexpr int CHP = NB1 * 32 + 4;   // bytes per channel plane: an odd number of dwords (conflict-free dword accesses across channels)
     static_assert((CHP / 4) % 2 == 1, "plane pitch");
     constexpr int DWP = LB_TW * 32 + 32;   // bytes per output row of dwo: odd and even rows fall on different banks
@@ -371,11 +374,15 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
     static_assert(N_ITEMS <= 2 * LB_NT, "two items per thread");
     __shared__ __attribute__((aligned(16))) char xs[NB1 * 32 * 32 * KS1];   // block input [window position][K]
     __shared__ __attribute__((aligned(16))) char vm[NB1 * 32];              // 0xff inside the image, 0 outside (and on padding positions)
-    __shared__ __attribute__((aligned(16))) char hidp[32 * CHP];            // quant_act1 output [channel of the slice][window position]
-    __shared__ __attribute__((aligned(16))) char dwo[LB_TH * DWP];          // quant_act2 output [output pixel][channel of the slice]
-    __shared__ __attribute__((aligned(16))) char stg[2][BUF];
+    // per group: hidp = quant_act1 output [channel of the slice][window position], dwo = quant_act2 output [output pixel][channel of
+    // the slice], two stages of tables + weights; the pool is reused for the cross-group sum of the projection accumulators
+    constexpr int HIDB = (32 * CHP + 15) / 16 * 16, DWOB = LB_TH * DWP, GRPB = HIDB + DWOB + 2 * BUF;
+    static_assert(NG == 1 || NG * GRPB >= (NG - 1) * LB_NT * 16 * 4, "reduction buffer fits the pool");
+    __shared__ __attribute__((aligned(16))) char pool[NG * GRPB];
     __shared__ v4i ct3s[32 * CT2];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tall = threadIdx.x, t = tall & (LB_NT - 1), grp = NG > 1 ? __builtin_amdgcn_readfirstlane(tall >> 8) : 0;
+    const int lane = t & 63, wave = t >> 6, gwave = tall >> 6, l31 = lane & 31, h = lane >> 5;
+    char *hidp = pool + grp * GRPB, *dwo = hidp + HIDB, *stg0 = dwo + DWOB;
     int bid = blockIdx.x;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
@@ -383,8 +390,8 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
     const int oy0 = ty * LB_TH, ox0 = tx * LB_TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const int8_t *img = p.x + (size_t)n * p.H * p.W * p.in_pitch;
 #pragma unroll
-    for (int i = 0; i < MAXB; ++i) {
-        const int blk = wave + 4 * i, pos = blk * 32 + l31;
+    for (int i = 0; i < MAXBP; ++i) {
+        const int blk = gwave + 4 * NG * i, pos = blk * 32 + l31;
         if (blk < NB1) {
             const int wy = pos / WWP, wx = pos - wy * WWP, iy = iy0 + wy, ix = ix0 + wx;
             const bool ok = wy < WH && wx < WW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -416,10 +423,12 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
         }
     }
     v4i sreg[2];
+    if (grp < p.nsl) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-        if (ssrc[r]) *reinterpret_cast<v4i *>(&stg[0][sdst[r]]) = ldg4(ssrc[r]);
-    if (t < 32 * CT2) ct3s[t] = ldg4(p.ct3 + t * 4);
+        for (int r = 0; r < 2; ++r)
+            if (ssrc[r]) *reinterpret_cast<v4i *>(stg0 + sdst[r]) = ldg4(ssrc[r] + (size_t)grp * sstep[r]);
+    }
+    if (tall < 32 * CT2) ct3s[tall] = ldg4(p.ct3 + tall * 4);
     v16i acc2[CT2];
 #pragma unroll
     for (int c = 0; c < CT2; ++c)
@@ -431,16 +440,17 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
     const size_t pix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
     __syncthreads();
 
-    for (int j = 0; j < p.nsl; ++j) {
-        const char *sb = stg[j & 1];
-        const bool more = j + 1 < p.nsl;
+    for (int jj = 0; jj * NG < p.nsl; ++jj) {
+        const int j = jj * NG + grp;
+        const bool act = j < p.nsl, more = j + NG < p.nsl;   // (uniform per group; the barriers below are the whole workgroup's)
+        const char *sb = stg0 + (jj & 1) * BUF;
         if (more) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
-                if (ssrc[r]) sreg[r] = ldg4(ssrc[r] + (size_t)(j + 1) * sstep[r]);
+                if (ssrc[r]) sreg[r] = ldg4(ssrc[r] + (size_t)(j + NG) * sstep[r]);
         }
         // ---------------------------------------------------------------- GEMM1 + quant_act1 -> hidp (this lane: channel l31)
-        {
+        if (act) {
             v4i wf[KS1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) wf[ks] = *reinterpret_cast<const v4i *>(sb + OFF_W1 + l31 * (32 * KS1) + ks * 32 + h * 16);
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
         }
         __syncthreads();   // B1: hidp complete; every wave is past GEMM2 of the previous slice
         // ---------------------------------------------------------------- depthwise 3x3 + quant_act2 -> dwo (this thread: channel dc, row doy)
-        {
+        if (act) {
             int acc[16];
 #pragma unroll
             for (int x = 0; x < 16; ++x) acc[x] = 0;
@@ -519,11 +529,11 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
         if (more) {
 #pragma unroll
             for (int r = 0; r < 2; ++r)
-                if (ssrc[r]) *reinterpret_cast<v4i *>(&stg[(j & 1) ^ 1][sdst[r]]) = sreg[r];
+                if (ssrc[r]) *reinterpret_cast<v4i *>(stg0 + ((jj & 1) ^ 1) * BUF + sdst[r]) = sreg[r];
         }
         __syncthreads();   // B2: dwo complete, hidp free, next stage complete
         // ---------------------------------------------------------------- GEMM2 partial sum over this slice
-        {
+        if (act) {
             const v4i af = *reinterpret_cast<const v4i *>(dwo + (pl >> 4) * DWP + (pl & 15) * 32 + h * 16);
 #pragma unroll
             for (int c = 0; c < CT2; ++c) {
@@ -533,6 +543,25 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
         }
     }
 
+    if constexpr (NG > 1) {   // sum of the groups' accumulators, one 32-channel block at a time: [group - 1][register][thread] ints in the pool
+        int *red = reinterpret_cast<int *>(pool);
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            __syncthreads();   // (first pass: every group is past its last GEMM2; later: the adds of the previous block are done)
+            if (grp > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((grp - 1) * 16 + r) * LB_NT + t] = acc2[c][r];
+            }
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int g = 1; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[c][r] += red[((g - 1) * 16 + r) * LB_NT + t];
+            }
+        }
+        if (grp > 0) return;
+    }
     // -------------------------------------------------------------------- closing: quant_act_int32 (+ identity), next QuantAct
     if (!out_ok) return;
     DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);
@@ -571,22 +600,31 @@ __global__ __launch_bounds__(LB_NT) void linear_bottleneck_planar_kernel(const L
 }
 
 typedef void (*LbFn)(const LbP);
-// organisation 1 ([pixel][channel]) exists for K steps / output blocks up to 2; the planar one up to 3 (96-channel inputs and outputs)
+template <int S, int KS1, int CT2, int NG>
+LbFn pick_planar(bool tie, bool k0h) {
+    if (k0h && !tie) return linear_bottleneck_planar_kernel<S, KS1, CT2, false, true, NG>;
+    return tie ? linear_bottleneck_planar_kernel<S, KS1, CT2, true, false, NG> : linear_bottleneck_planar_kernel<S, KS1, CT2, false, false, NG>;
+}
+// organisation 1 ([pixel][channel]) exists for K steps / output blocks up to 2; the planar one up to 3 (96-channel inputs and outputs);
+// slice groups (ng 2, 4) exist for stride 1 (the 14 x 14 maps are where workgroups are scarce)
 template <int S, int KS1, int CT2>
-LbFn pick_variant(bool tie, bool planar, bool k0h) {
+LbFn pick_variant(bool tie, bool planar, bool k0h, int ng) {
     if constexpr (KS1 <= 2 && CT2 <= 2) {
         if (!planar) return tie ? linear_bottleneck_kernel<S, KS1, CT2, true> : linear_bottleneck_kernel<S, KS1, CT2, false>;
     }
-    if (k0h && !tie) return linear_bottleneck_planar_kernel<S, KS1, CT2, false, true>;
-    return tie ? linear_bottleneck_planar_kernel<S, KS1, CT2, true, false> : linear_bottleneck_planar_kernel<S, KS1, CT2, false, false>;
+    if constexpr (S == 1) {
+        if (ng == 2) return pick_planar<S, KS1, CT2, 2>(tie, k0h);
+        if (ng == 4) return pick_planar<S, KS1, CT2, 4>(tie, k0h);
+    }
+    return pick_planar<S, KS1, CT2, 1>(tie, k0h);
 }
 template <int S, int KS1>
-LbFn pick_ct2(int ct2, bool tie, bool planar, bool k0h) {
-    return ct2 == 1 ? pick_variant<S, KS1, 1>(tie, planar, k0h) : ct2 == 2 ? pick_variant<S, KS1, 2>(tie, planar, k0h) : pick_variant<S, KS1, 3>(tie, planar, k0h);
+LbFn pick_ct2(int ct2, bool tie, bool planar, bool k0h, int ng) {
+    return ct2 == 1 ? pick_variant<S, KS1, 1>(tie, planar, k0h, ng) : ct2 == 2 ? pick_variant<S, KS1, 2>(tie, planar, k0h, ng) : pick_variant<S, KS1, 3>(tie, planar, k0h, ng);
 }
 template <int S>
-LbFn pick(int ks1, int ct2, bool tie, bool planar, bool k0h) {
-    return ks1 == 1 ? pick_ct2<S, 1>(ct2, tie, planar, k0h) : ks1 == 2 ? pick_ct2<S, 2>(ct2, tie, planar, k0h) : pick_ct2<S, 3>(ct2, tie, planar, k0h);
+LbFn pick(int ks1, int ct2, bool tie, bool planar, bool k0h, int ng) {
+    return ks1 == 1 ? pick_ct2<S, 1>(ct2, tie, planar, k0h, ng) : ks1 == 2 ? pick_ct2<S, 2>(ct2, tie, planar, k0h, ng) : pick_ct2<S, 3>(ct2, tie, planar, k0h, ng);
 }
 
 bool e_fast(int ek) { return (ek & 0xff) >= 33 && (ek & 0xff) <= 62 && (ek >> 8) >= 0 && (ek >> 8) < 31; }
@@ -613,7 +651,7 @@ const char *lb_refusal(const hawq_bottleneck_args *a) {
     if (!q.out_q && !q.res_out) return "nothing to write";
     const int H = e.H, W = e.W, Ho = (H - 1) / a->dw_stride + 1, Wo = (W - 1) / a->dw_stride + 1;
     if (q.N != e.N || q.H != Ho || q.W != Wo) return "project geometry must be the depthwise conv's output grid";
-    if (a->tile < 0 || a->tile > 2) return "tile: 0 (default), 1 or 2";
+    if (a->tile < 0 || a->tile > 4) return "tile: 0 (default) .. 4";
     if ((long long)e.N * ((Ho + LB_TH - 1) / LB_TH) * ((Wo + LB_TW - 1) / LB_TW) > 0x7fffffffll) return "grid too large";
     return nullptr;
 }
@@ -642,10 +680,15 @@ extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *strea
     p.tiles_x = (p.Wo + LB_TW - 1) / LB_TW, p.tiles_y = (p.Ho + LB_TH - 1) / LB_TH;
     const bool tie = ((e.fast_tables | a->dw_fast_tables | q.fast_tables) & 4) != 0;
     const int ks1 = (p.in_pitch + 31) / 32, ct2 = (p.out_pitch + 31) / 32;
-    const bool planar = a->tile != 1;   // tile 1: the [pixel][channel] organisation (A/B measurements); 0 / 2: the planar one
+    const bool planar = a->tile != 1;   // tile 1: the [pixel][channel] organisation (A/B measurements)
     const bool k0h = (e.fast_tables & 8) && (a->dw_fast_tables & 8);   // the caller's promise: no per-channel pre-shift in ctab / dw_ctab
-    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar, k0h) : pick<2>(ks1, ct2, tie, planar, k0h);
-    hipLaunchKernelGGL(fn, dim3(p.N * p.tiles_y * p.tiles_x), dim3(LB_NT), 0, (hipStream_t)stream, p);
+    // slice groups: tile 2 / 3 / 4 force 1 / 2 / 4; by default as many as bring the launch to about three waves per SIMD
+    const long long wgs = (long long)p.N * p.tiles_y * p.tiles_x;
+    int ng = a->tile == 2 ? 1 : a->tile == 3 ? 2 : a->tile == 4 ? 4 : (wgs >= 768 ? 1 : (wgs >= 384 ? 2 : 4));
+    if (!planar || a->dw_stride != 1) ng = 1;
+    while (ng > 1 && ng > p.nsl) ng >>= 1;
+    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar, k0h, ng) : pick<2>(ks1, ct2, tie, planar, k0h, ng);
+    hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(LB_NT * ng), 0, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;
 }

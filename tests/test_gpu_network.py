@@ -391,7 +391,7 @@ def test_mobilenetv2_concurrent_sub_batches_are_bit_identical():
             assert len(eng.subs) == 2 and [s._batch[0] for s in eng.subs] == [11, 10]
 
 
-@pytest.mark.parametrize("organisation", ["planar", "pixel_major"])
+@pytest.mark.parametrize("organisation", ["planar", "pixel_major", "planar_1_group", "planar_2_groups"])
 @pytest.mark.parametrize("scheme", ["uniform8", "bops_0.5"])
 @pytest.mark.parametrize("hw", [(224, 224), (72, 104)])
 def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, organisation, monkeypatch):
@@ -412,8 +412,11 @@ def test_mobilenetv2_one_launch_units_equal_three_launches(scheme, hw, organisat
     y3 = three(x).clone()
     assert three.n_fused_units == 0
     monkeypatch.delenv("HAWQ_MBV2_UNFUSED")
-    if organisation == "pixel_major":   # the launch's first organisation (hawq_bottleneck_args.tile = 1)
-        monkeypatch.setenv("HAWQ_MBV2_UNIT_TILE", "1")
+    # hawq_bottleneck_args.tile: 0 = planar hidden tensor, slice groups by the number of workgroups (4 groups on most units of this
+    # small batch); 1 = the launch's first organisation; 2 / 3 = planar with 1 / 2 slice groups
+    tile = {"planar": None, "pixel_major": "1", "planar_1_group": "2", "planar_2_groups": "3"}[organisation]
+    if tile is not None:
+        monkeypatch.setenv("HAWQ_MBV2_UNIT_TILE", tile)
     one = MobileNetV2Engine(model, chains=1, use_graph=False)
     y1 = one(x).clone()
     assert one.n_fused_units >= 7, one.n_fused_units   # units 1-10 of the width-1 network have <= 64-channel inputs and outputs
