@@ -55,33 +55,46 @@ __global__ __launch_bounds__(256) void stem3x3s2_kernel(const StemP p) {
         if (t < 192) reinterpret_cast<int *>(lut_s)[t] = reinterpret_cast<const int *>(p.lut)[t];
         __syncthreads();
     }
-    // 1. quantised window -> LDS
-    constexpr int NEL = 3 * ST_WH * ST_WW;
-    for (int idx = t; idx < NEL; idx += 256) {
-        int c, wy, wx;
-        if constexpr (U8) {   // (wy, wx, c): the NHWC bytes of a window row are contiguous
-            wy = idx / (3 * ST_WW);
-            const int r = idx - wy * (3 * ST_WW);
-            wx = r / 3, c = r - wx * 3;
-        } else {              // (c, wy, wx): the NCHW floats of a window row are contiguous
-            c = idx / (ST_WH * ST_WW);
-            const int r = idx - c * (ST_WH * ST_WW);
-            wy = r / ST_WW, wx = r - wy * ST_WW;
+    // 1. quantised window -> LDS.  A thread keeps its window column (fp32: wx = t % 36, seven groups of threads walk the 3 x 17 (channel,
+    //    row) pairs; uint8: byte t % 100 of the 99-byte NHWC window row, two groups walk the 17 rows): no per-element index arithmetic
+    //    beyond an add, and consecutive lanes read consecutive addresses.
+    if constexpr (U8) {
+        const int bx = t % 100, rg = t / 100, wx = bx / 3, c = bx - wx * 3, ix = ix0 + wx;
+        const bool mine = bx < 3 * ST_WW && rg < 2, cok = (unsigned)ix < (unsigned)p.W;
+        const int ixc = min(max(ix, 0), p.W - 1);
+        unsigned char u[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int iyc = min(max(iy0 + min(rg + 2 * i, ST_WH - 1), 0), p.H - 1);
+            u[i] = p.xu[(((size_t)n * p.H + iyc) * p.W + ixc) * 3 + c];
         }
-        const int iy = iy0 + wy, ix = ix0 + wx;
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        int q = 0;
-        if (ok) {
-            if constexpr (U8) {
-                q = lut_s[c * 256 + p.xu[(((size_t)n * p.H + iy) * p.W + ix) * 3 + c]];
-            } else {
-                const float v = p.x[(((size_t)n * 3 + c) * p.H + iy) * p.W + ix];
-                float rr = rintf(__fmul_rn(p.inv_scale, v));   // one binary32 rounding, as `1. / scale * input` has
-                rr = fminf(fmaxf(rr, (float)p.in_lo), (float)p.in_hi);
-                q = (int)rr;
-            }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int wy = rg + 2 * i;
+            const int q = (cok && (unsigned)(iy0 + wy) < (unsigned)p.H) ? (int)lut_s[c * 256 + u[i]] : 0;
+            if (mine && wy < ST_WH) qs[c * ST_PL + wy * ST_RP + wx] = (int8_t)q;
         }
-        qs[c * ST_PL + wy * ST_RP + wx] = (int8_t)q;
+    } else {
+        // all eight loads of a thread are issued before the first is used (clamped addresses, no branches around them)
+        const int wx = t % 36, rg = t / 36, ix = ix0 + wx;
+        const bool mine = wx < ST_WW && rg < 7, cok = (unsigned)ix < (unsigned)p.W;
+        const int ixc = min(max(ix, 0), p.W - 1);
+        const float flo = (float)p.in_lo, fhi = (float)p.in_hi;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = min(rg + 7 * i, 3 * ST_WH - 1), c = pr / ST_WH, wy = pr - c * ST_WH;   // (channel, window row) pair rg + 7 i
+            const int iyc = min(max(iy0 + wy, 0), p.H - 1);
+            v[i] = p.x[(((size_t)n * 3 + c) * p.H + iyc) * p.W + ixc];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pr = rg + 7 * i, c = pr / ST_WH, wy = pr - c * ST_WH;
+            float rr = rintf(__fmul_rn(p.inv_scale, v[i]));   // one binary32 rounding, as `1. / scale * input` has
+            rr = fminf(fmaxf(rr, flo), fhi);
+            const int q = (cok && (unsigned)(iy0 + wy) < (unsigned)p.H) ? (int)rr : 0;
+            if (mine && pr < 3 * ST_WH) qs[c * ST_PL + wy * ST_RP + wx] = (int8_t)q;
+        }
     }
     __syncthreads();
     // 2. this lane's half of its pixel's patch: taps 16 h .. 16 h + 15
