@@ -19,17 +19,25 @@ Integer semantics (reference: q_mobilenetv2.py:60-93, 176-209; quant_utils.py:36
     clamp: the QuantAct's calibrated range cannot exceed 6, so ``RNE(round(6 / S_a / S_w[c]) * m / 2^e) >= q_hi`` and the clamp
     at ``q_hi`` decides first.  ``_relu6_is_relu`` checks exactly that inequality per channel on the host and refuses the
     plan otherwise;
-  * channel counts are padded to multiples of 64 with zero weights, zero bias and ``m = 0`` tables: padded channels carry exact
-    zeros through every tensor;
+  * weights and tables are padded to multiples of 64 channels with zero weights, zero bias and ``m = 0`` tables; tensors are stored at
+    the next multiple of 16 channels, their padding channels carry exact zeros;
   * the classifier is a QuantConv2d whose reference forward runs an fp32 conv on the UN-rounded ``x / S_a``
     (quant_modules.py:727-736): its logits carry float noise of the order of an ulp.  This plan returns
     ``float(acc) * fl(S_w[c] * S_a)``: identical int32 accumulators, logits within 2 ulp (tests/test_gpu_network.py).
 
-The unit-closing convs (signed carriers) run the exact general epilogue (``fast_tables = 0``: any e, ties handled; ``n_valid``
-skips the padding channels); the expansion convs run the host-proved fast requant contract; the depthwise layers run
-``hawq_depthwise3x3_requant``; the input QuantAct writes the init conv's im2col rows (fp32 or, ``forward_uint8``, uint8 images
-through a look-up table).  Every ``hawq_conv2d`` launch is tile-tuned by timing, and the batch runs as one or two concurrent
-sub-batch chains inside the one hipGraph, whichever replays faster (36.5 k -> 97 k img/s over round 3).
+Round 4 (97 k -> 193 k img/s at batch 128):
+  * a unit whose three layers' requant tables the host proves for the fast contract and whose block input / output are at most 96
+    channels wide is ONE launch (``hawq_linear_bottleneck``: the hidden tensors stay in LDS) - 13 of the 17 units of the width-1
+    network; the init block is one launch too (``hawq_stem3x3s2``, fp32 or uint8 images);
+  * the remaining units run three launches on tensors stored at their own width (``hawq_conv_args.in_pitch / out_pitch``, ABI 4),
+    their closing convs with the fast contract's arithmetic on the direct epilogue where every table of the launch is proved
+    (otherwise the exact general epilogue: any e, ties handled; ``n_valid`` skips the padding channels); the expansion convs run the
+    fast REQUANT epilogue, the depthwise layers ``hawq_depthwise3x3_requant``;
+  * tapped plans (``keep_accumulators``) always run the round-3 launch list - the taps ARE the intermediate tensors.
+Every ``hawq_conv2d`` launch is tile-tuned by timing, and the batch runs as one or two concurrent sub-batch chains inside the one
+hipGraph, whichever replays faster.  Switches (results never change): HAWQ_MBV2_UNFUSED=1 three launches per unit and the im2col init
+block; HAWQ_MBV2_UNIT_TILE=1..4 organisation of the unit launch (``hawq_bottleneck_args.tile``); HAWQ_MBV2_EXACT=1 exact closing
+epilogues; HAWQ_MBV2_PAD64=1 round 3's 64-padded tensors; HAWQ_MBV2_CHAINS, HAWQ_MBV2_TILES.
 """
 from __future__ import annotations
 
