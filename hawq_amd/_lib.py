@@ -82,6 +82,7 @@ SIGNATURES = {
     "hawq_conv2d_grouped": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "hawq_depthwise3x3": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "hawq_depthwise3x3_requant": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp],
+    "hawq_depthwise3x3_requant_fast": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "hawq_quantize_im2col3x3s2": [vp, vp, i32, i32, i32, i32, f32, i32, i32, vp],
     "hawq_quantize_im2col3x3s2_u8": [vp, vp, vp, i32, i32, i32, i32, vp],
     "hawq_resample_u8": [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp],

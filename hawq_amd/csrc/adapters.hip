@@ -238,8 +238,11 @@ namespace {
 constexpr int DW_PX = 4;
 constexpr int DW_MAX_BAND = 8;
 
-// REQ: conv2 -> ReLU -> QuantAct fused (exact dyadic_rne per channel table), int8 out; `out` (int32) then optional
-template <bool REQ, int S>
+// REQ: conv2 -> ReLU -> QuantAct fused (exact dyadic_rne per channel table), int8 out; `out` (int32) then optional.
+// FASTQ (round 4, hawq_depthwise3x3_requant_fast): 1 / 2 = the fast requant contract (2: with the exact-tie correction) against fused
+// constants [C][4] (bias folded in) passed through `mult`: 3-4 instructions per output instead of dyadic_rne's ~20 - the requants were
+// more than half of this kernel's instructions on the 7 x 7 maps.
+template <bool REQ, int S, int FASTQ = 0>
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restrict__ in, const int8_t *__restrict__ w9c, const int32_t *__restrict__ bias,
                                                            int N, int H, int W, int C, int Cv, int Ho, int Wo, int band, int32_t *__restrict__ out,
                                                            const int32_t *__restrict__ mult, const int32_t *__restrict__ expo, int relu, int q_lo, int q_hi,
@@ -263,9 +266,18 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) wm[t][j] = ww & (0xff << (8 * j));
         }
-        const v4i b4 = bias ? *reinterpret_cast<const v4i *>(bias + 4 * cg) : v4i{0, 0, 0, 0};
+        const v4i b4 = (bias && FASTQ == 0) ? *reinterpret_cast<const v4i *>(bias + 4 * cg) : v4i{0, 0, 0, 0};
         v4i m4 = {0, 0, 0, 0}, e4 = {0, 0, 0, 0};
-        if constexpr (REQ) m4 = *reinterpret_cast<const v4i *>(mult + 4 * cg), e4 = *reinterpret_cast<const v4i *>(expo + 4 * cg);
+        DyNt dq[4];
+        if constexpr (REQ && FASTQ == 0) m4 = *reinterpret_cast<const v4i *>(mult + 4 * cg), e4 = *reinterpret_cast<const v4i *>(expo + 4 * cg);
+        if constexpr (REQ && FASTQ != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4i t4 = *reinterpret_cast<const v4i *>(mult + (size_t)(4 * cg + j) * 4);
+                dq[j].m = t4.x, dq[j].s = t4.y & 31, dq[j].k = t4.y >> 8;
+                dq[j].add = (long long)(((unsigned long long)(unsigned)t4.w << 32) | (unsigned)t4.z);
+            }
+        }
         // column offsets (clamped) and validity of the NC input columns
         int coff[NC];
         unsigned cmask = 0;
@@ -313,7 +325,10 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restr
                     if constexpr (REQ) {
                         int qv[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) qv[j] = clampi(dyadic_rne(relu ? max(acc[p][j], 0) : acc[p][j], m4[j], e4[j]), q_lo, q_hi);
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (FASTQ == 0) qv[j] = clampi(dyadic_rne(relu ? max(acc[p][j], 0) : acc[p][j], m4[j], e4[j]), q_lo, q_hi);
+                            else qv[j] = med3i(FASTQ == 2 ? dyadic_tie(acc[p][j], dq[j]) : dyadic_nt(acc[p][j], dq[j]), q_lo, q_hi);   // ReLU is in q_lo >= 0
+                        }
                         *reinterpret_cast<uint32_t *>(out_q + o4) = pack4_i8(qv[0], qv[1], qv[2], qv[3]);
                     }
                     for (int pc = cgv + cg; pc < cgs; pc += cgv) {   // padding groups: rne(0 * 0) = 0
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const int8_t *__restr
     }
 }
 
-template <bool REQ>
+template <bool REQ, int FASTQ = 0>
 int depthwise_launch(const int8_t *in, const int8_t *wgt9c, const int32_t *bias, const int32_t *m, const int32_t *e, int N, int H, int W, int C, int Cv, int stride,
                      int relu, int q_lo, int q_hi, int8_t *out_q, int32_t *out_acc, void *stream) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
@@ -348,7 +363,7 @@ int depthwise_launch(const int8_t *in, const int8_t *wgt9c, const int32_t *bias,
     if (band > Ho) band = Ho;
     const long long total = per_row * ((Ho + band - 1) / band);
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    auto kern = stride == 1 ? depthwise3x3_kernel<REQ, 1> : depthwise3x3_kernel<REQ, 2>;
+    auto kern = stride == 1 ? depthwise3x3_kernel<REQ, 1, FASTQ> : depthwise3x3_kernel<REQ, 2, FASTQ>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, wgt9c, bias, N, H, W, C, Cv, Ho, Wo, (int)band, out_acc, m, e, relu, q_lo, q_hi,
                        out_q);
     HAWQ_CHECK_HIP(hipGetLastError());
@@ -372,6 +387,19 @@ extern "C" int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, 
     HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3_requant: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
     HAWQ_REQUIRE(q_lo >= -128 && q_hi <= 127 && q_lo <= q_hi, "hawq_depthwise3x3_requant: the clamp must fit int8");
     return depthwise_launch<true>(in, wgt9c, bias, m, e, N, H, W, C, C_valid > 0 ? C_valid : C, stride, relu, q_lo, q_hi, out_q, out_acc, stream);
+}
+
+extern "C" int hawq_depthwise3x3_requant_fast(const int8_t *in, const int8_t *wgt9c, const int32_t *ctab, int32_t fast_tables, int32_t N, int32_t H, int32_t W,
+                                              int32_t C, int32_t C_valid, int32_t stride, int32_t q_lo, int32_t q_hi, int8_t *out_q, void *stream) {
+    HAWQ_REQUIRE(in && wgt9c && ctab && out_q, "hawq_depthwise3x3_requant_fast: null pointer");
+    HAWQ_REQUIRE(fast_tables != 0, "hawq_depthwise3x3_requant_fast: fast_tables = 0 is hawq_depthwise3x3_requant");
+    HAWQ_REQUIRE(C_valid >= 0 && C_valid <= C, "hawq_depthwise3x3_requant_fast: C_valid=%d outside [0, C=%d]", C_valid, C);
+    HAWQ_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "hawq_depthwise3x3_requant_fast: need C %% 4 == 0 and stride 1 or 2 (C=%d stride=%d)", C, stride);
+    HAWQ_REQUIRE(q_lo >= 0 && q_hi <= 127 && q_lo <= q_hi, "hawq_depthwise3x3_requant_fast: the clamp carries the ReLU: 0 <= q_lo <= q_hi <= 127");
+    HAWQ_REQUIRE(C_valid == 0 || C_valid == C || q_lo == 0, "hawq_depthwise3x3_requant_fast: padding channels are written as 0, which the clamp must contain");
+    const int cv = C_valid > 0 ? C_valid : C;
+    if (fast_tables & 4) return depthwise_launch<true, 2>(in, wgt9c, nullptr, ctab, nullptr, N, H, W, C, cv, stride, 1, q_lo, q_hi, out_q, nullptr, stream);
+    return depthwise_launch<true, 1>(in, wgt9c, nullptr, ctab, nullptr, N, H, W, C, cv, stride, 1, q_lo, q_hi, out_q, nullptr, stream);
 }
 
 

@@ -484,7 +484,7 @@ class MobileNetV2Engine:
             keep += [xq_f, xq]
 
         def closing(L, m, e, x, n, h, w, res_in, m_id, e_id, relu, clamp16, nxt_q, name, need16=True, fast=None, id_fast=None, q_fast=None,
-                    unit=None, stem=None):
+                    unit=None, stem=None, carrier16=False):
             """conv + unit-closing 16-bit QuantAct (+ the next block-input QuantAct) -> (int32 tensor, int8 q, ho, wo);
             the 32-bit carrier is only written where something reads it (the next unit's identity, the pool, a tap).
             ``unit`` = dict(x, h, w, conv1 entry, conv2 entry): the whole unit as ONE launch (hawq_linear_bottleneck) - x is then the
@@ -494,13 +494,14 @@ class MobileNetV2Engine:
             a = self._conv_args(L, (x if unit is None else unit['x']) if stem is None else self.x_in, n, h, w)
             a.epilogue, a.m, a.e = _lib.EPI_RESIDUAL, m.data_ptr(), e.data_ptr()
             out16 = None
+            u16 = bool(carrier16 and relu and clamp16 and not self.keep_acc)   # post-ReLU, clamped: 0 .. 32767 fits the uint16 carrier
             if need16 or self.keep_acc:
-                out16 = alloc(n * ho * wo * L.cout_s, torch.int32)
-                a.res_out, a.res_out_bits = out16.data_ptr(), 32
+                out16 = alloc(n * ho * wo * L.cout_s, torch.int16 if u16 else torch.int32)
+                a.res_out, a.res_out_bits = out16.data_ptr(), (16 if u16 else 32)
             in_bytes = h * w * L.cin if unit is None else unit['h'] * unit['w'] * unit['e1']['layer'].cin   # (the hidden tensors stay on chip)
             if stem is not None:
                 in_bytes = 0   # (the images are already counted; no patch rows)
-            self.plan_bytes += n * (in_bytes + ho * wo * L.cout * ((4 if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
+            self.plan_bytes += n * (in_bytes + ho * wo * L.cout * (((2 if u16 else 4) if need16 else 0) + (1 if nxt_q is not None else 0) + (4 if res_in is not None else 0))) + L.weight_bytes
             use_fast = (fast is not None and (res_in is None or id_fast is not None) and (nxt_q is None or q_fast is not None)
                         and not os.environ.get("HAWQ_MBV2_EXACT"))
             if res_in is not None:
@@ -601,9 +602,14 @@ class MobileNetV2Engine:
                     acc = alloc(N * ho * wo * L.cout_s, torch.int32) if self.keep_acc else None
                     if acc is not None:
                         self.taps[lname] = (acc, (N, ho, wo, L.cout_s), L.cout)
-                    ops.append(partial(_lib.call, "hawq_depthwise3x3_requant", x.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), ent['m'].data_ptr(),
-                                       ent['e'].data_ptr(), N, h, w, L.cout_s, L.cout, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
-                                       None if acc is None else acc.data_ptr(), sp))
+                    if acc is None and 'dw_ctab' in ent and ent['hi'] <= 127 and not os.environ.get("HAWQ_MBV2_EXACT"):
+                        # the host-proved short requant (the accumulator tap needs the exact launch's second output)
+                        ops.append(partial(_lib.call, "hawq_depthwise3x3_requant_fast", x.data_ptr(), L.w.data_ptr(), ent['dw_ctab'].data_ptr(), ent['dw_fast'] & 7,
+                                           N, h, w, L.cout_s, L.cout, L.stride, ent['lo'], ent['hi'], out.data_ptr(), sp))
+                    else:
+                        ops.append(partial(_lib.call, "hawq_depthwise3x3_requant", x.data_ptr(), L.w.data_ptr(), L.bias.data_ptr(), ent['m'].data_ptr(),
+                                           ent['e'].data_ptr(), N, h, w, L.cout_s, L.cout, L.stride, 1, ent['lo'], ent['hi'], out.data_ptr(),
+                                           None if acc is None else acc.data_ptr(), sp))
                     keep.append(acc)
                 self.plan_bytes += N * (h * w * L.cin + ho * wo * L.cout) + L.weight_bytes
                 self.taps[lname + ":q"] = (out, (N, ho, wo, L.cout_s), L.cout)
@@ -613,14 +619,15 @@ class MobileNetV2Engine:
                                    False, not u['residual'], nq, name + ".conv3", need16=bool(nxt is not None and nxt['residual']),
                                    fast=pr['fast'], id_fast=u.get('id_fast'), q_fast=nq_fast)
         fin = P['final']
-        x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block", fast=fin['fast'])
+        # (the final block's values are post-ReLU and clamped: a uint16 carrier halves what the pool reads)
+        x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block", fast=fin['fast'], carrier16=True)
         cl = fin['layer'].cout_s
         if cl != fin['layer'].cout_p:
             raise NotImplementedError("the final block's width must be a multiple of 64 (the pool and the classifier read dense rows)")
         qf = alloc(N * cl, torch.int8)
         pooled = alloc(N * cl, torch.int32) if self.keep_acc else None
         o = P['out']
-        ops.append(partial(_lib.call, "hawq_avgpool_requant", x16.data_ptr(), 32, N, h * w, cl, qf.data_ptr(), None if pooled is None else pooled.data_ptr(),
+        ops.append(partial(_lib.call, "hawq_avgpool_requant", x16.data_ptr(), 16 if x16.dtype == torch.int16 else 32, N, h * w, cl, qf.data_ptr(), None if pooled is None else pooled.data_ptr(),
                            o['mq'], o['eq'], o['rng'][0], o['rng'][1], sp))
         fc = P['fc']
         if fc['k'] != cl:

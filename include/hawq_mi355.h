@@ -278,6 +278,12 @@ int hawq_depthwise3x3_requant(const int8_t *in, const int8_t *wgt9c, const int32
                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t C_valid, int32_t stride, int32_t relu, int32_t q_lo,
                               int32_t q_hi, int8_t *out_q, int32_t *out_acc, void *stream);
 
+/* The same launch with the fast requant contract (round 4): ctab [C][4] = the fused constants of the layer's requant with the bias folded in
+ * (hawq_amd.packing.pack_ctab), fast_tables with the meaning it has in hawq_conv_args: 1, or 5 = exact ties (the host proves the contract, hawq_amd.quant_utils);
+ * ReLU is the lower clamp (q_lo >= 0).  3-4 instructions per requant instead of the exact form's ~20. */
+int hawq_depthwise3x3_requant_fast(const int8_t *in, const int8_t *wgt9c, const int32_t *ctab, int32_t fast_tables, int32_t N, int32_t H, int32_t W,
+                                   int32_t C, int32_t C_valid, int32_t stride, int32_t q_lo, int32_t q_hi, int8_t *out_q, void *stream);
+
 /* One launch per linear-bottleneck unit of MobileNetV2 (Q_LinearBottleneck.forward, q_mobilenetv2.py:59-93; round 4):
  *   block-input int8 -> conv1 1x1 (+ReLU6 + quant_act1) -> conv2 depthwise 3x3 / stride 1|2 / pad 1 (+ReLU6 + quant_act2)
  *   -> conv3 1x1 -> quant_act_int32 (with / without the identity branch) -> the next block-input QuantAct,

@@ -302,3 +302,32 @@ def test_stem3x3s2_against_the_oracle(lib, orc, hw, u8):
     assert lib.load().hawq_stem3x3s2(keep['x'].data_ptr(), keep['x'].data_ptr(), None, H, W, float(inv_s), -128, 127, C.byref(a), None) != 0
     a.H += 1
     assert lib.load().hawq_stem3x3s2(*args, C.byref(a), None) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 7, 32, 32, 1), (1, 14, 14, 96, 96, 2), (3, 7, 7, 160, 144, 1), (1, 113, 57, 32, 24, 2)])
+@pytest.mark.parametrize("tie", [False, True])
+def test_depthwise3x3_requant_fast_against_the_oracle(lib, orc, shape, tie):
+    """hawq_depthwise3x3_requant_fast: depthwise 3x3 + ReLU + QuantAct with the host-proved short requant (fused constants, bias folded
+    in) - against the oracle's depthwise conv + round-half-even dyadic; tie: the exact-tie instantiation (exact for any table)."""
+    from oracle import oracle_mbv2
+    n, h, w, pitch, c, stride = shape
+    rng = np.random.default_rng(h * w + c + tie)
+    x = rng.integers(0, 128, (n, c, h, w)).astype(np.int64)
+    wt = rng.integers(-127, 128, (c, 1, 3, 3)).astype(np.int64)
+    b = rng.integers(-3000, 3000, c).astype(np.int64)
+    m, ek, ctab, f = fast_table(rng.uniform(0.6, 1.6, c) * 127 / (np.abs(wt).reshape(c, -1).sum(1) * 40 + 1), 1.0, b, np.abs(wt).reshape(c, -1).sum(1), pitch)
+    ref = odyadic(orc, np.maximum(oracle_mbv2.depthwise3x3(x, wt, b, stride), 0), m, ek, (0, 100))
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    w9 = np.zeros((9, pitch), np.int8)
+    w9[:, :c] = wt.reshape(c, 9).T
+    keep = dict(x=dev(stored(x, pitch, rng)), w=dev(w9))
+    if pitch > c:   # padding channels of a stored activation tensor are zeros
+        keep['x'][:n * h * w * pitch].view(-1, pitch)[:, c:] = 0
+    out = torch.full((n * ho * wo * pitch,), 7, dtype=torch.int8, device='cuda')
+    lib.call("hawq_depthwise3x3_requant_fast", keep['x'].data_ptr(), keep['w'].data_ptr(), ctab.data_ptr(), (f & 7) | (4 if tie else 0), n, h, w, pitch, c, stride,
+             0, 100, out.data_ptr(), stream())
+    assert np.array_equal(unstored(out, n, ho, wo, pitch, c), ref)
+    assert not unstored(out, n, ho, wo, pitch, pitch)[:, c:].any()
+    assert (ref == 100).any() and (ref == 0).any()
+    assert lib.load().hawq_depthwise3x3_requant_fast(keep['x'].data_ptr(), keep['w'].data_ptr(), ctab.data_ptr(), 0, n, h, w, pitch, c, stride, 0, 100, out.data_ptr(), None) != 0
+    assert lib.load().hawq_depthwise3x3_requant_fast(keep['x'].data_ptr(), keep['w'].data_ptr(), ctab.data_ptr(), 1, n, h, w, pitch, c, stride, -5, 100, out.data_ptr(), None) != 0
