@@ -25,7 +25,7 @@ Integer semantics (reference: q_mobilenetv2.py:60-93, 176-209; quant_utils.py:36
     (quant_modules.py:727-736): its logits carry float noise of the order of an ulp.  This plan returns
     ``float(acc) * fl(S_w[c] * S_a)``: identical int32 accumulators, logits within 2 ulp (tests/test_gpu_network.py).
 
-Round 4 (97 k -> 193 k img/s at batch 128):
+Round 4 (97 k -> 201 k img/s at batch 128):
   * a unit whose three layers' requant tables the host proves for the fast contract and whose block input / output are at most 96
     channels wide is ONE launch (``hawq_linear_bottleneck``: the hidden tensors stay in LDS) - 13 of the 17 units of the width-1
     network; the init block is one launch too (``hawq_stem3x3s2``, fp32 or uint8 images);
