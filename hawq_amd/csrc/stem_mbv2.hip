@@ -62,11 +62,14 @@ __global__ __launch_bounds__(256) void stem3x3s2_kernel(const StemP p) {
         const int bx = t % 100, rg = t / 100, wx = bx / 3, c = bx - wx * 3, ix = ix0 + wx;
         const bool mine = bx < 3 * ST_WW && rg < 2, cok = (unsigned)ix < (unsigned)p.W;
         const int ixc = min(max(ix, 0), p.W - 1);
+        // (24-bit multiplies: full-rate VALU; image rows / planes are far below 2^24 elements)
+        const uint8_t *xb = p.xu + (size_t)n * p.H * p.W * 3 + ixc * 3 + c;
+        const unsigned w3 = (unsigned)p.W * 3;
         unsigned char u[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int iyc = min(max(iy0 + min(rg + 2 * i, ST_WH - 1), 0), p.H - 1);
-            u[i] = p.xu[(((size_t)n * p.H + iyc) * p.W + ixc) * 3 + c];
+            u[i] = xb[__umul24((unsigned)iyc, w3)];
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -80,16 +83,19 @@ __global__ __launch_bounds__(256) void stem3x3s2_kernel(const StemP p) {
         const bool mine = wx < ST_WW && rg < 7, cok = (unsigned)ix < (unsigned)p.W;
         const int ixc = min(max(ix, 0), p.W - 1);
         const float flo = (float)p.in_lo, fhi = (float)p.in_hi;
+        // (no divisions, 24-bit multiplies: the integer arithmetic of these addresses was a third of the kernel's VALU time)
+        const unsigned hw = (unsigned)p.H * (unsigned)p.W;
+        const float *xb = p.x + (size_t)n * 3 * hw + ixc;
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int pr = min(rg + 7 * i, 3 * ST_WH - 1), c = pr / ST_WH, wy = pr - c * ST_WH;   // (channel, window row) pair rg + 7 i
+            const int pr = min(rg + 7 * i, 3 * ST_WH - 1), c = (pr >= ST_WH) + (pr >= 2 * ST_WH), wy = pr - c * ST_WH;   // (channel, window row) pair rg + 7 i
             const int iyc = min(max(iy0 + wy, 0), p.H - 1);
-            v[i] = p.x[(((size_t)n * 3 + c) * p.H + iyc) * p.W + ixc];
+            v[i] = xb[__umul24((unsigned)c, hw) + __umul24((unsigned)iyc, (unsigned)p.W)];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int pr = rg + 7 * i, c = pr / ST_WH, wy = pr - c * ST_WH;
+            const int pr = rg + 7 * i, c = (pr >= ST_WH) + (pr >= 2 * ST_WH), wy = pr - c * ST_WH;
             float rr = rintf(__fmul_rn(p.inv_scale, v[i]));   // one binary32 rounding, as `1. / scale * input` has
             rr = fminf(fmaxf(rr, flo), fhi);
             const int q = (cok && (unsigned)(iy0 + wy) < (unsigned)p.H) ? (int)rr : 0;
