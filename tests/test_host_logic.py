@@ -80,6 +80,34 @@ SCRATCH_ALLOWED = {
 }
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The ctypes mirrors of hawq_conv_args / hawq_expand_reduce_args / hawq_bottleneck_args (hawq_amd/_lib.py) against the C compiler's
+    own layout of include/hawq_mi355.h: size and the offset of EVERY field (a field added on one side only, or in another order, would
+    silently shift every argument behind it)."""
+    import ctypes
+    import subprocess
+    from hawq_amd import _lib
+    structs = {"hawq_conv_args": _lib.ConvArgs, "hawq_expand_reduce_args": _lib.ExpandReduceArgs, "hawq_bottleneck_args": _lib.BottleneckArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "hawq_mi355.h")}"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {"in" if fname == "in_" else fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    # and the header declares no field the mirror lacks: the C struct has exactly as many members as the mirror has bytes accounted for
+    hdr = open(os.path.join(ROOT, "include", "hawq_mi355.h")).read()
+    assert f"#define HAWQ_ABI_VERSION {_lib.load().hawq_abi_version()}" in hdr
+
+
 def test_shipped_kernels_do_not_spill():
     from hawq_amd import _lib
     _lib.load()
