@@ -362,16 +362,21 @@ __device__ __forceinline__ int requant_h(int v, const DyNt &d) {
 // NG: slice groups.  Maps with few tiles (14 x 14 at batch 128: one workgroup per CU) leave one wave per SIMD and every latency of the
 // per-slice chain exposed; with NG > 1 the workgroup has NG x 4 waves, group g walks slices g, g + NG, .. with its own hidp / dwo /
 // stage buffers (the block-input window is shared) and the groups' projection accumulators are summed through LDS at the end.
-template <int S, int KS1, int CT2, bool TIE, bool K0H, int NG>
+// TW: tile width.  16 everywhere but on the 7 x 7 maps, where an 8 x 8 tile holds one whole image (77 % of its pixels real, against 38 % of an
+// 8 x 16 tile) and the wide units there (160 -> 960 -> 160 / 320 channels) spread the projection over the waves by (pixel block,
+// output-channel blocks) instead of pixel blocks alone: TH * TW / 32 pixel blocks x 4 / that many groups of output blocks.
+template <int S, int KS1, int CT2, bool TIE, bool K0H, int NG, int TW = LB_TW>
 __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(const LbP p) {
-    constexpr int WH = (LB_TH - 1) * S + 3, WW = (LB_TW - 1) * S + 3, WWP = (WW + 3) / 4 * 4, NPOS = WH * WWP, NB1 = (NPOS + 31) / 32;
+    static_assert(TW == 16 || TW == 8, "tile width");
+    constexpr int NPB = LB_TH * TW / 32, NCG = 4 / NPB, CTW = (CT2 + NCG - 1) / NCG;   // pixel blocks, output-block groups, output blocks per wave
+    constexpr int WH = (LB_TH - 1) * S + 3, WW = (TW - 1) * S + 3, WWP = (WW + 3) / 4 * 4, NPOS = WH * WWP, NB1 = (NPOS + 31) / 32;
     constexpr int MAXB = (NB1 + 3) / 4, MAXBP = (NB1 + 4 * NG - 1) / (4 * NG);
     constexpr int CHP = NB1 * 32 + 4;   // bytes per channel plane: an odd number of dwords (conflict-free dword accesses across channels)
     static_assert((CHP / 4) % 2 == 1, "plane pitch");
-    constexpr int DWP = LB_TW * 32 + 32;   // bytes per output row of dwo: odd and even rows fall on different banks
+    constexpr int DWP = TW * 32 + 32;   // bytes per output row of dwo: odd and even rows fall on different banks
     constexpr int N_W1 = 64 * KS1, N_W9 = 18, N_W3 = 64 * CT2, N_ITEMS = 64 + N_W1 + N_W9 + N_W3;   // 16-byte items per slice
     constexpr int OFF_CT1 = 0, OFF_CT2 = 512, OFF_W1 = 1024, OFF_W9 = OFF_W1 + 1024 * KS1, OFF_W3 = OFF_W9 + 288, BUF = OFF_W3 + 1024 * CT2;
-    static_assert(N_ITEMS <= 2 * LB_NT, "two items per thread");
+    constexpr int NSR = (N_ITEMS + LB_NT - 1) / LB_NT;   // staged 16-byte items per thread and slice
     __shared__ __attribute__((aligned(16))) char xs[NB1 * 32 * 32 * KS1];   // block input [window position][K]
     __shared__ __attribute__((aligned(16))) char vm[NB1 * 32];              // 0xff inside the image, 0 outside (and on padding positions)
     // per group: hidp = quant_act1 output [channel of the slice][window position], dwo = quant_act2 output [output pixel][channel of
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y, n = bid / p.tiles_y;
-    const int oy0 = ty * LB_TH, ox0 = tx * LB_TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int oy0 = ty * LB_TH, ox0 = tx * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const int8_t *img = p.x + (size_t)n * p.H * p.W * p.in_pitch;
 #pragma unroll
     for (int i = 0; i < MAXBP; ++i) {
@@ -401,10 +406,10 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
             if (h == 0) vm[pos] = ok ? (char)0xff : (char)0;
         }
     }
-    const char *ssrc[2];
-    int sstep[2], sdst[2];
+    const char *ssrc[NSR];
+    int sstep[NSR], sdst[NSR];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NSR; ++r) {
         const int it = t + r * LB_NT;
         ssrc[r] = nullptr, sstep[r] = 0, sdst[r] = 0;
         if (it < 32) {
@@ -422,20 +427,21 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
             ssrc[r] = (const char *)p.w3 + (size_t)(k >> 1) * p.w3_pitch + (k & 1) * 16, sstep[r] = 32, sdst[r] = OFF_W3 + k * 16;
         }
     }
-    v4i sreg[2];
+    v4i sreg[NSR];
     if (grp < p.nsl) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < NSR; ++r)
             if (ssrc[r]) *reinterpret_cast<v4i *>(stg0 + sdst[r]) = ldg4(ssrc[r] + (size_t)grp * sstep[r]);
     }
-    if (tall < 32 * CT2) ct3s[tall] = ldg4(p.ct3 + tall * 4);
-    v16i acc2[CT2];
+    for (int i = tall; i < 32 * CT2; i += LB_NT * NG) ct3s[i] = ldg4(p.ct3 + i * 4);
+    v16i acc2[CTW];
 #pragma unroll
-    for (int c = 0; c < CT2; ++c)
+    for (int c = 0; c < CTW; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
     const int dc = t & 31, doy = t >> 5;   // depthwise: this thread's channel (== l31) and output row
-    const int pl = wave * 32 + l31, gy = oy0 + (pl >> 4), gx = ox0 + (pl & 15);
+    // projection: this wave's pixel block and its first output block (then every NCG-th); this lane's output pixel
+    const int pb = wave % NPB, cgw = wave / NPB, pl = pb * 32 + l31, py = pl / TW, px = pl % TW, gy = oy0 + py, gx = ox0 + px;
     const bool out_ok = gy < p.Ho && gx < p.Wo;
     const size_t pix = ((size_t)n * p.Ho + gy) * p.Wo + gx;
     __syncthreads();
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
         const char *sb = stg0 + (jj & 1) * BUF;
         if (more) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < NSR; ++r)
                 if (ssrc[r]) sreg[r] = ldg4(ssrc[r] + (size_t)(j + NG) * sstep[r]);
         }
         // ---------------------------------------------------------------- GEMM1 + quant_act1 -> hidp (this lane: channel l31)
@@ -483,9 +489,9 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
         __syncthreads();   // B1: hidp complete; every wave is past GEMM2 of the previous slice
         // ---------------------------------------------------------------- depthwise 3x3 + quant_act2 -> dwo (this thread: channel dc, row doy)
         if (act) {
-            int acc[16];
+            int acc[TW];
 #pragma unroll
-            for (int x = 0; x < 16; ++x) acc[x] = 0;
+            for (int x = 0; x < TW; ++x) acc[x] = 0;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const unsigned char *wp = reinterpret_cast<const unsigned char *>(sb + OFF_W9 + kh * 96 + dc);
@@ -494,11 +500,11 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
                 if constexpr (S == 1) {
                     // output x = 4 q + r reads bytes x .. x + 2 of the row: inside dword q for r = 0, 1; across q and q + 1 for r = 2, 3
                     const int w0 = (int)wa, w1 = (int)(wa << 8), w2a = (int)(wa << 16), w2b = (int)(wa >> 16), w3a = (int)(wa << 24), w3b = (int)(wa >> 8);
-                    int r[5];
+                    int r[TW / 4 + 1];
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) r[q] = rowp[q];
+                    for (int q = 0; q < TW / 4 + 1; ++q) r[q] = rowp[q];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < TW / 4; ++q) {
                         acc[4 * q] = __builtin_amdgcn_sdot4(r[q], w0, acc[4 * q], false);
                         acc[4 * q + 1] = __builtin_amdgcn_sdot4(r[q], w1, acc[4 * q + 1], false);
                         acc[4 * q + 2] = __builtin_amdgcn_sdot4(r[q], w2a, acc[4 * q + 2], false);
@@ -509,11 +515,11 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
                 } else {
                     // output x reads bytes 2 x .. 2 x + 2: inside dword x / 2 for even x; across x / 2 and x / 2 + 1 for odd x
                     const int w0 = (int)wa, w1a = (int)(wa << 16), w1b = (int)(wa >> 16);
-                    int r[9];
+                    int r[TW / 2 + 1];
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) r[q] = rowp[q];
+                    for (int q = 0; q < TW / 2 + 1; ++q) r[q] = rowp[q];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
+                    for (int q = 0; q < TW / 2; ++q) {
                         acc[2 * q] = __builtin_amdgcn_sdot4(r[q], w0, acc[2 * q], false);
                         acc[2 * q + 1] = __builtin_amdgcn_sdot4(r[q], w1a, acc[2 * q + 1], false);
                         acc[2 * q + 1] = __builtin_amdgcn_sdot4(r[q + 1], w1b, acc[2 * q + 1], false);
@@ -524,21 +530,24 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
             asm volatile("" : "+v"(d2.add));
             char *dst = dwo + doy * DWP + dc;
 #pragma unroll
-            for (int x = 0; x < 16; ++x) dst[x * 32] = (char)med3i(requant_h<TIE, K0H>(acc[x], d2), p.lo2, p.hi2);
+            for (int x = 0; x < TW; ++x) dst[x * 32] = (char)med3i(requant_h<TIE, K0H>(acc[x], d2), p.lo2, p.hi2);
         }
         if (more) {
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < NSR; ++r)
                 if (ssrc[r]) *reinterpret_cast<v4i *>(stg0 + ((jj & 1) ^ 1) * BUF + sdst[r]) = sreg[r];
         }
         __syncthreads();   // B2: dwo complete, hidp free, next stage complete
         // ---------------------------------------------------------------- GEMM2 partial sum over this slice
         if (act) {
-            const v4i af = *reinterpret_cast<const v4i *>(dwo + (pl >> 4) * DWP + (pl & 15) * 32 + h * 16);
+            const v4i af = *reinterpret_cast<const v4i *>(dwo + py * DWP + px * 32 + h * 16);
 #pragma unroll
-            for (int c = 0; c < CT2; ++c) {
-                const v4i wf = *reinterpret_cast<const v4i *>(sb + OFF_W3 + (c * 32 + cperm(l31)) * 32 + h * 16);
-                acc2[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc2[c], 0, 0, 0);
+            for (int ci = 0; ci < CTW; ++ci) {
+                const int c = cgw + ci * NCG;
+                if (c < CT2) {
+                    const v4i wf = *reinterpret_cast<const v4i *>(sb + OFF_W3 + (c * 32 + cperm(l31)) * 32 + h * 16);
+                    acc2[ci] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, af, acc2[ci], 0, 0, 0);
+                }
             }
         }
     }
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
     if constexpr (NG > 1) {   // sum of the groups' accumulators, one 32-channel block at a time: [group - 1][register][thread] ints in the pool
         int *red = reinterpret_cast<int *>(pool);
 #pragma unroll
-        for (int c = 0; c < CT2; ++c) {
+        for (int c = 0; c < CTW; ++c) {
             __syncthreads();   // (first pass: every group is past its last GEMM2; later: the adds of the previous block are done)
             if (grp > 0) {
 #pragma unroll
@@ -569,9 +578,9 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
     const int clo = p.clamp16 ? -32768 : (int)0x80000000, chi = p.clamp16 ? 32767 : 0x7fffffff;
     auto close = [&](auto with_identity) {
 #pragma unroll
-        for (int c = 0; c < CT2; ++c) {
-            const int ch = c * 32 + h * 16;
-            if (ch >= p.out_pitch) continue;
+        for (int ci = 0; ci < CTW; ++ci) {
+            const int c = cgw + ci * NCG, ch = c * 32 + h * 16;
+            if (c >= CT2 || ch >= p.out_pitch) continue;
             const size_t elem = pix * p.out_pitch + ch;
             int qw[4];
 #pragma unroll
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(LB_NT * NG) void linear_bottleneck_planar_kernel(co
                 for (int k = 0; k < 4; ++k) {
                     DyNt d = entry(ct3s[ch + 4 * g + k]);
                     asm volatile("" : "+v"(d.add));
-                    int ov = requant<TIE>(acc2[c][4 * g + k], d);
+                    int ov = requant<TIE>(acc2[ci][4 * g + k], d);
                     if (decltype(with_identity)::value) ov += requant<TIE>(rin[k], dids);
                     ov = med3i(ov, clo, chi);
                     o[k] = ov;
@@ -618,6 +627,22 @@ LbFn pick_variant(bool tie, bool planar, bool k0h, int ng) {
     }
     return pick_planar<S, KS1, CT2, 1>(tie, k0h);
 }
+// the 8 x 8 tile family: the wide units on maps of at most 8 x 8 pixels (MobileNetV2 w1 units 14-17), two slice groups
+template <int S, int KS1, int CT2, int NG>
+LbFn pick_t8_variant(bool tie, bool k0h) {
+    if (k0h && !tie) return linear_bottleneck_planar_kernel<S, KS1, CT2, false, true, NG, 8>;
+    return tie ? linear_bottleneck_planar_kernel<S, KS1, CT2, true, false, NG, 8> : linear_bottleneck_planar_kernel<S, KS1, CT2, false, false, NG, 8>;
+}
+LbFn pick_t8(int stride, int ks1, int ct2, bool tie, bool k0h, int *ng) {
+    int dummy;
+    if (!ng) ng = &dummy;
+    if (stride == 1 && ks1 == 5 && ct2 == 5) return *ng = 4, pick_t8_variant<1, 5, 5, 4>(tie, k0h);
+    if (stride == 1 && ks1 == 5 && ct2 == 10) return *ng = 2, pick_t8_variant<1, 5, 10, 2>(tie, k0h);
+    if (stride == 2 && ks1 == 3 && ct2 == 5) return *ng = 2, pick_t8_variant<2, 3, 5, 2>(tie, k0h);
+    return nullptr;
+}
+bool lb_wide(int ip, int op) { return ip > 96 || op > 96; }
+
 template <int S, int KS1>
 LbFn pick_ct2(int ct2, bool tie, bool planar, bool k0h, int ng) {
     return ct2 == 1 ? pick_variant<S, KS1, 1>(tie, planar, k0h, ng) : ct2 == 2 ? pick_variant<S, KS1, 2>(tie, planar, k0h, ng) : pick_variant<S, KS1, 3>(tie, planar, k0h, ng);
@@ -640,9 +665,9 @@ const char *lb_refusal(const hawq_bottleneck_args *a) {
     if (q.epilogue != HAWQ_EPI_RESIDUAL || !q.fast_tables || !q.res_no_relu) return "project: signed RESIDUAL epilogue (res_no_relu) with fast_tables";
     if (!a->dw_fast_tables || (a->dw_stride != 1 && a->dw_stride != 2)) return "depthwise: fast tables, stride 1 or 2";
     const int ip = e.in_pitch ? e.in_pitch : e.Cin, op = q.out_pitch ? q.out_pitch : q.Cout;
-    if ((e.Cin != 64 && e.Cin != 128) || (ip != 16 && ip != 32 && ip != 64 && ip != 96) || ip > e.Cin) return "expand: K = 64 / 128 packed weights, in_pitch 16 / 32 / 64 / 96";
+    if (e.Cin % 64 || e.Cin > 192 || (ip != 16 && ip != 32 && ip != 64 && ip != 96 && ip != 160) || ip > e.Cin) return "expand: K = 64 / 128 / 192 packed weights, in_pitch 16 / 32 / 64 / 96 / 160";
     if (e.Cout <= 0 || e.Cout % 64 || q.Cin != e.Cout || a->c_mid <= 0 || a->c_mid > e.Cout) return "hidden width: expand.Cout == project.Cin, a multiple of 64, c_mid inside it";
-    if ((q.Cout != 64 && q.Cout != 128) || (op != 16 && op != 32 && op != 64 && op != 96) || op > q.Cout) return "project: Cout = 64 / 128 packed rows, out_pitch 16 / 32 / 64 / 96";
+    if (q.Cout % 64 || q.Cout > 320 || (op != 16 && op != 32 && op != 64 && op != 96 && op != 160 && op != 320) || op > q.Cout) return "project: Cout = 64 .. 320 packed rows, out_pitch 16 / 32 / 64 / 96 / 160 / 320";
     if (a->tile == 1 && (ip > 64 || op > 64)) return "tile 1 (the [pixel][channel] organisation) takes at most 64-channel inputs and outputs";
     if (e.q_hi < 0 || e.q_hi > 127 || a->dw_q_lo < 0 || a->dw_q_hi < a->dw_q_lo || a->dw_q_hi > 127) return "hidden activations must be 0 .. 127 int8 (ReLU in the clamp)";
     if (q.out_q && (q.out_bits != 8 || q.q_lo < -128 || q.q_hi > 127 || q.q_lo > q.q_hi || q.mq < 0 || !e_fast(q.eq))) return "project: int8 out_q with a fast (mq, eq)";
@@ -652,6 +677,11 @@ const char *lb_refusal(const hawq_bottleneck_args *a) {
     const int H = e.H, W = e.W, Ho = (H - 1) / a->dw_stride + 1, Wo = (W - 1) / a->dw_stride + 1;
     if (q.N != e.N || q.H != Ho || q.W != Wo) return "project geometry must be the depthwise conv's output grid";
     if (a->tile < 0 || a->tile > 4) return "tile: 0 (default) .. 4";
+    if (lb_wide(ip, op)) {   // more than 96 channels in or out: the 8 x 8 tile family, maps of at most 8 x 8 output pixels, at least four slices (one per slice group)
+        if (a->tile == 1) return "tile 1 (the [pixel][channel] organisation) takes at most 64-channel inputs and outputs";
+        if (Ho > 8 || Wo > 8 || a->c_mid <= 96) return "inputs / outputs wider than 96 channels: output maps of at most 8 x 8 pixels only";
+        if (!pick_t8(a->dw_stride, (ip + 31) / 32, (op + 31) / 32, false, false, nullptr)) return "no instantiation for this wide unit (160 -> 160 / 320 at stride 1, 96 -> 160 at stride 2)";
+    }
     if ((long long)e.N * ((Ho + LB_TH - 1) / LB_TH) * ((Wo + LB_TW - 1) / LB_TW) > 0x7fffffffll) return "grid too large";
     return nullptr;
 }
@@ -677,7 +707,9 @@ extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *strea
     p.res_out = (int32_t *)q.res_out, p.out_q = (int8_t *)q.out_q;
     p.mq = q.out_q ? q.mq : 0, p.eq = q.out_q ? q.eq : 33, p.q_lo = q.q_lo, p.q_hi = q.q_hi, p.clamp16 = q.res_clamp16;
     p.out_pitch = q.out_pitch ? q.out_pitch : q.Cout;
-    p.tiles_x = (p.Wo + LB_TW - 1) / LB_TW, p.tiles_y = (p.Ho + LB_TH - 1) / LB_TH;
+    const bool wide = lb_wide(p.in_pitch, p.out_pitch);
+    const int tw = wide ? 8 : LB_TW;
+    p.tiles_x = (p.Wo + tw - 1) / tw, p.tiles_y = (p.Ho + LB_TH - 1) / LB_TH;
     const bool tie = ((e.fast_tables | a->dw_fast_tables | q.fast_tables) & 4) != 0;
     const int ks1 = (p.in_pitch + 31) / 32, ct2 = (p.out_pitch + 31) / 32;
     const bool planar = a->tile != 1;   // tile 1: the [pixel][channel] organisation (A/B measurements)
@@ -687,7 +719,10 @@ extern "C" int hawq_linear_bottleneck(const hawq_bottleneck_args *a, void *strea
     int ng = a->tile == 2 ? 1 : a->tile == 3 ? 2 : a->tile == 4 ? 4 : (wgs >= 768 ? 1 : (wgs >= 384 ? 2 : 4));
     if (!planar || a->dw_stride != 1) ng = 1;
     while (ng > 1 && ng > p.nsl) ng >>= 1;
-    LbFn fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar, k0h, ng) : pick<2>(ks1, ct2, tie, planar, k0h, ng);
+    LbFn fn;
+    if (wide) fn = pick_t8(a->dw_stride, ks1, ct2, tie, k0h, &ng);
+    else fn = a->dw_stride == 1 ? pick<1>(ks1, ct2, tie, planar, k0h, ng) : pick<2>(ks1, ct2, tie, planar, k0h, ng);
+    HAWQ_REQUIRE(fn, "hawq_linear_bottleneck: no kernel for this unit");
     hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(LB_NT * ng), 0, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     return 0;

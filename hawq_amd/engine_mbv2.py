@@ -25,10 +25,10 @@ Integer semantics (reference: q_mobilenetv2.py:60-93, 176-209; quant_utils.py:36
     (quant_modules.py:727-736): its logits carry float noise of the order of an ulp.  This plan returns
     ``float(acc) * fl(S_w[c] * S_a)``: identical int32 accumulators, logits within 2 ulp (tests/test_gpu_network.py).
 
-Round 4 (97 k -> 201 k img/s at batch 128):
+Round 4 (97 k -> 209 k img/s at batch 128):
   * a unit whose three layers' requant tables the host proves for the fast contract and whose block input / output are at most 96
-    channels wide is ONE launch (``hawq_linear_bottleneck``: the hidden tensors stay in LDS) - 13 of the 17 units of the width-1
-    network; the init block is one launch too (``hawq_stem3x3s2``, fp32 or uint8 images);
+    channels wide (or, on the 7 x 7 maps, 160) is ONE launch (``hawq_linear_bottleneck``: the hidden tensors stay in LDS) - 16 of the
+    17 units of the width-1 network; the init block is one launch too (``hawq_stem3x3s2``, fp32 or uint8 images);
   * the remaining units run three launches on tensors stored at their own width (``hawq_conv_args.in_pitch / out_pitch``, ABI 4),
     their closing convs with the fast contract's arithmetic on the direct epilogue where every table of the launch is proved
     (otherwise the exact general epilogue: any e, ties handled; ``n_valid`` skips the padding channels); the expansion convs run the
@@ -354,10 +354,11 @@ class MobileNetV2Engine:
         a.out_pitch = L.cout_s if L.cout_s != L.cout_p else 0   # (RAW taps reset it: the accumulators are dense [M][Cout])
         return a
 
-    def _one_launch(self, u, nq_fast) -> bool:
+    def _one_launch(self, u, nq_fast, h, w) -> bool:
         """Does this unit run as one hawq_linear_bottleneck launch?  Needs: conv1 1x1 + depthwise 3x3 + conv3 1x1 with every requant
         table proved for the fast contract, block input and output at most 96 channels wide (the launch keeps the projection's
-        accumulators of an 8 x 16 pixel tile in registers).  HAWQ_MBV2_UNFUSED=1: three launches per unit everywhere (A/B switch);
+        accumulators of an 8 x 16 pixel tile in registers) - or, on output maps of at most 8 x 8 pixels, the 160 / 320-channel units of
+        the width-1 network (8 x 8 tiles, the projection spread over the waves by output blocks; (h, w) = the unit's input map).  HAWQ_MBV2_UNFUSED=1: three launches per unit everywhere (A/B switch);
         tapped plans (keep_accumulators) always run the three launches - the taps ARE the intermediate tensors."""
         if self.keep_acc or os.environ.get("HAWQ_MBV2_UNFUSED") or os.environ.get("HAWQ_MBV2_EXACT") or os.environ.get("HAWQ_MBV2_PAD64"):
             return False
@@ -371,8 +372,15 @@ class MobileNetV2Engine:
             return False
         if u['residual'] and u.get('id_fast') is None:
             return False
-        wide = (16, 32, 64) if os.environ.get("HAWQ_MBV2_UNIT_TILE") == "1" else (16, 32, 64, 96)
-        return L1.cin_p in (64, 128) and L3.cout_p in (64, 128) and L1.cin_s in wide and L3.cout_s in wide and e1['hi'] <= 127 and e2['hi'] <= 127
+        if e1['hi'] > 127 or e2['hi'] > 127:
+            return False
+        narrow = (16, 32, 64) if os.environ.get("HAWQ_MBV2_UNIT_TILE") == "1" else (16, 32, 64, 96)
+        if L1.cin_s in narrow and L3.cout_s in narrow:
+            return True
+        # wider units: the launch's 8 x 8 tile family - output maps of at most 8 x 8 pixels (the 7 x 7 maps of the 224 x 224 network)
+        ho, wo = (h - 1) // L2.stride + 1, (w - 1) // L2.stride + 1
+        return (os.environ.get("HAWQ_MBV2_UNIT_TILE") != "1" and not os.environ.get("HAWQ_MBV2_NO_WIDE_UNITS") and ho <= 8 and wo <= 8 and L2.cout > 96
+                and (L1.cin_s, L3.cout_s, L2.stride) in ((160, 160, 1), (96, 160, 2)))   # (the launch also takes 160 -> 320: 34 us against 29 us as three launches)
 
     def _tap(self, ops, keep, name, a, N, ho, wo, cout, cout_p):
         """extra RAW launch exposing the conv's int32 accumulators (tests only)"""
@@ -571,7 +579,7 @@ class MobileNetV2Engine:
             nq = (nxt['mq'], nxt['eq'], nxt['q_rng']) if nxt is not None else (P['before_final']['mq'], P['before_final']['eq'], P['before_final']['rng'])
             nq_fast = nxt['q_fast'] if nxt is not None else P['before_final']['q_fast']
             pr = u['proj']
-            if self._one_launch(u, nq_fast):
+            if self._one_launch(u, nq_fast, h, w):
                 e1, e2 = u['layers']
                 s2 = e2['layer'].stride
                 ho, wo = (h - 1) // s2 + 1, (w - 1) // s2 + 1

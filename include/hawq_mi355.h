@@ -291,7 +291,8 @@ int hawq_depthwise3x3_requant_fast(const int8_t *in, const int8_t *wgt9c, const 
  * 1x1 expand conv on the tile's halo window, runs the depthwise taps out of LDS and feeds the projection GEMM from LDS, 32 hidden
  * channels at a time.  Same integers as the three launches (hawq_conv2d REQUANT, hawq_depthwise3x3_requant, hawq_conv2d RESIDUAL).
  *   expand:  as for hawq_conv2d with the REQUANT epilogue and fast_tables != 0 (ctab, q_lo / q_hi, relu = 1); 1x1 / stride 1; Cin is the
- *            K of its packed weights (64 or 128), in_pitch in {16, 32, 64, 96} (0 = Cin); Cout = the hidden width padded to 64; out_q is
+ *            K of its packed weights (64 or 128; 192 for the wide units below), in_pitch in {16, 32, 64, 96} (0 = Cin); Cout = the hidden
+ *            width padded to 64; out_q is
  *            ignored.  fast_tables bit 3 on BOTH expand and dw_fast_tables (no per-channel pre-shift in ctab / dw_ctab) selects the
  *            instantiation without the shift.
  *   dw_*:    wgt9c [9][expand.Cout] int8 tap-major (zero beyond the real channels); dw_ctab [expand.Cout][4] fused constants of its
@@ -302,6 +303,8 @@ int hawq_depthwise3x3_requant_fast(const int8_t *in, const int8_t *wgt9c, const 
  *            int8 (optional), mq / eq / q_lo / q_hi; Cin == expand.Cout; Cout = 64 or 128 packed rows, out_pitch in {16, 32, 64, 96}
  *            (0 = Cout); `in` is ignored.
  *   c_mid:   real hidden channels (channels >= c_mid of every hidden-side table / weight are zero padding).
+ *   Wide units: on output maps of at most 8 x 8 pixels the launch also takes in_pitch 160 -> out_pitch 160 or 320 at stride 1 and
+ *            in_pitch 96 -> out_pitch 160 at stride 2 (c_mid > 96): 8 x 8 tiles, the projection spread over the waves by output blocks.
  * hawq_linear_bottleneck_ok: 1 when this launch takes the unit as described, else 0 (use the three launches). */
 typedef struct hawq_bottleneck_args {
     hawq_conv_args expand;

@@ -176,7 +176,11 @@ UNITS = [(32, 32, 32, 16, 16, 1, False, (2, 20, 37), False),       # unit 1 of t
          (64, 64, 384, 64, 64, 1, True, (3, 14, 14), False),       # 12 slices, 64-wide input and output
          (32, 32, 192, 64, 64, 2, False, (2, 28, 28), False),
          (96, 96, 576, 96, 96, 1, True, (2, 14, 14), False),       # three K steps, three output blocks (planar organisation only)
-         (64, 64, 384, 96, 96, 1, False, (1, 7, 9), True)]
+         (64, 64, 384, 96, 96, 1, False, (1, 7, 9), True),
+         (160, 160, 960, 160, 160, 1, True, (2, 7, 7), False),      # the 7 x 7 units of the width-1 network: 8 x 8 tiles, 5 K steps, 5 output blocks
+         (160, 160, 960, 320, 320, 1, False, (1, 7, 7), False),     # ten output blocks
+         (96, 96, 576, 160, 160, 2, False, (2, 14, 14), False),     # stride 2 onto a 7 x 7 map
+         (160, 160, 128, 160, 160, 1, True, (1, 5, 8), True)]       # as many slices as slice groups, a ragged map, pre-shifts
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
@@ -190,6 +194,8 @@ def test_linear_bottleneck_against_the_oracle(lib, orc, unit, tile):
     cin, ipitch, hid, cout, opitch, stride, identity, (n, h, w), small = unit
     if tile == 1 and (ipitch > 64 or opitch > 64):
         pytest.skip("the first organisation takes at most 64-channel inputs and outputs")
+    if tile > 1 and (ipitch > 96 or opitch > 96):
+        pytest.skip("the wide units have one organisation (8 x 8 tiles, two slice groups)")
     rng = np.random.default_rng(cin + hid + cout + stride)
     cin_p, hid_p, cout_p = (cin + 63) // 64 * 64, (hid + 63) // 64 * 64, (cout + 63) // 64 * 64
     x = rng.integers(0, 128, (n, cin, h, w)).astype(np.int64)
@@ -203,7 +209,7 @@ def test_linear_bottleneck_against_the_oracle(lib, orc, unit, tile):
     # requant ratios that use the 0 .. 127 range of the hidden activations (and saturate some of them)
     m1, e1, ct1, f1 = fast_table(rng.uniform(0.6, 1.6, hid) * 127 / (np.abs(w1).reshape(hid, -1).sum(1) * 40 + 1), 1.0, b1, np.abs(w1).reshape(hid, -1).sum(1), hid_p)
     m2, e2, ct2, f2 = fast_table(rng.uniform(0.6, 1.6, hid) * 127 / (np.abs(w2).reshape(hid, -1).sum(1) * 40 + 1), 1.0, b2, np.abs(w2).reshape(hid, -1).sum(1), hid_p)
-    m3, e3, ct3, f3 = fast_table(rng.uniform(0.5, 3.0, cout) * (45000 if identity else 150000) / (np.abs(w3).reshape(cout, -1).sum(1) * 30 + 1), 1.0, b3,
+    m3, e3, ct3, f3 = fast_table(rng.uniform(0.5, 3.0, cout) * (45000 if identity else 150000) * (2 if hid >= 900 else 1) / (np.abs(w3).reshape(cout, -1).sum(1) * 30 + 1), 1.0, b3,
                                  np.abs(w3).reshape(cout, -1).sum(1), cout_p)
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     res = rng.integers(-30000, 30000, (n, cout, h, w)).astype(np.int64) if identity else None

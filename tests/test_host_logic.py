@@ -73,6 +73,10 @@ SCRATCH_ALLOWED = {
     # fused expand -> reduce, C = 64 / C = 128 with producers, all-k-zero instantiations at the 128-register budget
     "expand_reduce_kernelINS_5ERCfgILi64ELi2ELi0ELb1ELi4ELb0EEELb0ELb1": 3,
     "expand_reduce_kernelINS_5ERCfgILi128ELi2ELi4ELb1ELi4ELb0EEELb0ELb1": 1,
+    # MobileNetV2's 160 -> 960 -> 160 units on the 7 x 7 maps with FOUR slice groups (16 waves per workgroup: 128 registers): three projection
+    # accumulator tiles + five K steps of operands; one register pair is reloaded per slice (in loop).  Measured 29 us against 35.7 us for
+    # the two-group form without spills (profiles/r04_h_mbv2_wide_units.txt)
+    "linear_bottleneck_planar_kernelILi1ELi5ELi5E": 6,
     # hawq4 (nibble) 3x3 band kernels, 256 x 128 tiles: 64 accumulators + unpacked fragments at 128 registers.  The 384-pixel-band
     # form reloads one register pair per filter-row step (in loop) - W4A4's 14x14 / 7x7 conv2 launches; open item
     "conv3x3_band_kernelINS_7BandCfgILi256ELi128ELi4ELi2ELi512ELi2ELi1ELi8ELi3EEELb1": 2,
