@@ -37,6 +37,7 @@ class ConvArgs(C.Structure):
         ("in_planar", i32), ("out_planar", i32),
         ("res_no_relu", i32), ("res_clamp16", i32),
         ("in_pitch", i32), ("out_pitch", i32),
+        ("wgt_band", vp),
     ]
 
 
@@ -59,6 +60,9 @@ SIGNATURES = {
     "hawq_conv2d_num_tiles": [],
     "hawq_conv2d_num_band_tiles": [],
     "hawq_conv2d_band_tile": [C.POINTER(ConvArgs)],
+    "hawq_conv2d_num_band2_tiles": [],
+    "hawq_conv2d_band2_tile": [C.POINTER(ConvArgs)],
+    "hawq_pack_w3x3_band": [vp, vp, i32, i32],
     "hawq_conv_expand_reduce": [C.POINTER(ExpandReduceArgs), vp],
     "hawq_conv_expand_reduce_variants": [C.POINTER(ExpandReduceArgs)],
     "hawq_linear_bottleneck": [C.POINTER(BottleneckArgs), vp],
@@ -129,7 +133,7 @@ def load():
         fn.restype = C.c_int
     lib.hawq_last_error.restype = C.c_char_p
     lib.hawq_last_error.argtypes = []
-    if lib.hawq_abi_version() != 4:
+    if lib.hawq_abi_version() != 5:
         raise HawqLibraryError("libhawq_mi355.so ABI version mismatch")
     _lib = lib
     return lib

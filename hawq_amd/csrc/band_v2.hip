@@ -1,0 +1,402 @@
+// Round 5: 3x3 / stride 1 / pad 1 convolution (QuantBnConv2d + ReLU + QuantAct, quant_modules.py:489-494, 527-545, 233-260; the
+// second conv of every ResNet50 bottleneck, q_resnet.py:241-243, and both convs of a ResNet18/34 basic block, :300-306) rebuilt
+// around what tools/ubench/dma_issue.hip measured on gfx950 (profiles/r05_ubench_dma_issue.txt):
+//   * an LDS-DMA instruction costs the CU's vector-memory path ~2 cycles per 128-byte LINE it touches (min 16 per KiB): sixteen
+//     64-byte row segments a filter row apart - the shape every weight tile had so far - cap a CU at 28-32 B/clk, a contiguous
+//     KiB runs at 56-64 B/clk;
+//   * ONE wave that issues its pieces back to back ingests 45-65 GB/s; rounds 1-4 believed a wave was capped at 6-10 GB/s (the
+//     probe that said so divided 64-bit integers per issue) and spent 4-8 producer waves per workgroup on it.
+// Therefore:
+//   * weights are packed on the host into the exact byte stream a workgroup consumes: [Cout/64][slice][kh][kw][64 rows][64 B],
+//     rows pre-swizzled for conflict-free fragment reads, so a filter-row step is 12 contiguous KiB (hawq_pack_w3x3_band);
+//   * activations arrive as channel-group planes (hawq_conv_args.in_planar), 64 pixels of a plane = one contiguous KiB;
+//     `buffer_load ... lds` with a per-lane 32-bit offset: lanes of the zero columns / rows outside the tensor point beyond
+//     num_records and the hardware writes zeros (no zero page, no 64-bit address arithmetic);
+//   * 2-4 producer waves instead of 8 leave the register file to the MFMA waves: 3 waves per SIMD at <= 168 registers;
+//   * every MFMA wave owns a 64 px x 64 ch accumulator tile (2 x 2 MFMA tiles: ONE ds_read_b128 per MFMA; the 64 px x 32 ch
+//     wave tiles of the round-3 small tiles needed 1.5 and were LDS-bound) and the waves of a workgroup split K between them:
+//     wave group g takes k-half g (channels 32g .. 32g+31 of every 64-channel slice), so a 128-pixel tile still has 4 MFMA
+//     waves and a 256-pixel tile 8.  The two partial accumulator sets meet once, after the K loop, through LDS, each wave
+//     keeping one 32-pixel half - which also halves the requantisation work per wave;
+//   * the epilogue needs no staging tile: a lane holds 16 consecutive channels of one pixel = one 16-byte store (NHWC rows)
+//     or 32 lanes x 16 B = 512 contiguous bytes (planes).
+// Steps, ring and barriers follow conv3x3_band_kernel (conv_igemm.hip): one step = one filter row of one 64-channel slice
+// (3 taps), W ring of WS stages issued WS - 1 steps ahead, band double-buffered per slice, one s_barrier per step, the first
+// fragments of step s + 1 requested before the barrier that closes step s.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+struct B2P {
+    const char *in;        // planes [Cin/16][M][16 B] int8
+    const char *wgt;       // hawq_pack_w3x3_band stream
+    const int32_t *ctab;   // [Cout][4]
+    char *out;             // NHWC [M][Cout] int8, or planes [Cout/16][M][16 B]
+    const char *res_in;    // RESIDUAL: [M][Cout] uint16
+    char *res_out;         // RESIDUAL: [M][Cout] uint16 or null
+    int *flags;
+    int M, rows_total, Ho, Wo, Cin, Cout;
+    int nsteps, cchunks;
+    int out_planar, q_lo, q_hi;
+    int mq, eq, m_id, e_id;
+    unsigned in_bytes, wgt_bytes;
+    int dbg;
+    long long *dbgbuf;
+};
+
+template <int WM_, int NPROD_, int WS_, int BAND_PX_, int MINW_>
+struct V2Cfg {
+    static constexpr int WM = WM_, NPROD = NPROD_, WS = WS_, BAND_PX = BAND_PX_, MINW = MINW_;   // MINW: waves per SIMD the register budget is cut for
+    static constexpr int BM = 64 * WM, NW = 2 * WM, NT = (NW + NPROD) * 64;
+    static constexpr int PLANE = BAND_PX * 16, BAND_BYTES = 4 * PLANE;
+    static constexpr int WTAP = 4096, WSTAGE = 3 * WTAP;
+    static constexpr int OFF_W = 2 * BAND_BYTES, RING_END = OFF_W + WS * WSTAGE;
+    // the 128-pixel tile must fit 80 KiB twice per CU: its requant constants land in the first ring stage the K loop releases for
+    // good; the larger tiles have the CU to themselves and own a KiB for them
+    static constexpr bool CTAB_IN_RING = WM == 2;
+    static constexpr int LDS_BYTES = RING_END + (CTAB_IN_RING ? 0 : 1024);
+    static constexpr int PG = BAND_PX / 64;             // 64-pixel groups per plane
+    static constexpr int PPP = 4 / NPROD;               // planes per producer wave
+    static constexpr int BPI = PG * PPP, WPI = 12 / NPROD;
+    static constexpr int XCH = 8192;                    // exchange area per MFMA wave: 32 registers x 64 lanes x 4 B
+    static_assert(NPROD == 2 || NPROD == 4, "producer waves");
+    static_assert(BAND_PX % 64 == 0 && WS >= 4 && WS <= 5, "ring");
+    static_assert(NW * XCH <= (CTAB_IN_RING ? 2 * BAND_BYTES : RING_END), "the partial-sum exchange reuses the band area (and the ring)");
+};
+
+__device__ __forceinline__ void bdma(__amdgpu_buffer_rsrc_t r, char *lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)lds, 16, voff, soff, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_upto(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform n in [0, N]
+    if constexpr (N == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (n >= N) wait_vmcnt<N>(); else wait_vm_upto<N - 1>(n);
+    }
+}
+
+// EPI: HAWQ_EPI_REQUANT, or HAWQ_EPI_RESIDUAL (single branch, uint16 residuals: the second conv of a basic block).
+// MODE: 0 = tie-free tables, 2 = exact-tie correction on every requant (fast_tables bit 2).
+template <class C, int EPI, int MODE>
+__global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bool prof = HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf;
+    const long long t_entry = prof ? (long long)__builtin_readcyclecounter() : 0;
+    const int tiles_c = p.Cout >> 6;
+    const int nwg = ((p.M + C::BM - 1) / C::BM) * tiles_c;
+    int wg = blockIdx.x;
+    {   // each XCD (id mod 8) owns a contiguous run of tiles: the channel tiles of a pixel tile share its band in that L2
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tc = wg % tiles_c, tm = wg / tiles_c;
+    const int m0 = tm * C::BM, c0 = tc << 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: role and k-half branches are scalar branches
+    const int Wo = p.Wo, Wb = Wo + 2;
+    const int G0 = m0 / Wo - 1;   // global row (n * Ho + y) held by band row 0
+    const int mlast = (m0 + C::BM < p.M ? m0 + C::BM : p.M) - 1;
+    const int brows = mlast / Wo - G0 + 2;   // band rows the tile's pixels touch (their own rows + one halo row each side)
+    const int zp = brows * Wb;               // band pixels zp .. zp + 3 of every plane are zeros (launcher: zp + 4 <= BAND_PX)
+    const int npg = (zp + 4 + 63) >> 6;      // 64-pixel groups of a plane that are filled at all
+    const int nsteps = p.nsteps, cchunks = p.cchunks;
+    char *const band = smem, *const wring = smem + C::OFF_W;
+    char *const ctab_lds = C::CTAB_IN_RING ? wring + (nsteps % C::WS) * C::WSTAGE : smem + C::RING_END;
+
+    if (wave >= C::NW) {
+        // ------------------------------------------------------------------ producer waves: every LDS-DMA of the kernel
+        const int dw = wave - C::NW;
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)p.in_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, (int)p.wgt_bytes, 0x00020000);
+        unsigned bvo[C::PG];   // byte offset of this lane's pixel inside a plane, or out of range (the hardware then writes zeros)
+#pragma unroll
+        for (int g = 0; g < C::PG; ++g) {
+            const int bpx = g * 64 + lane;
+            const int br = bpx / Wb, bc = bpx - br * Wb;
+            const int G = G0 + br, x = bc - 1;
+            const bool v = (unsigned)G < (unsigned)p.rows_total && (unsigned)x < (unsigned)Wo && br < brows;
+            bvo[g] = v ? (unsigned)(G * Wo + x) * 16u : 0x80000000u;
+        }
+        const unsigned wvo = (unsigned)(dw * 1024 + lane * 16);
+        const unsigned plane_bytes = (unsigned)p.M * 16u;
+        const unsigned wbase = (unsigned)tc * (unsigned)nsteps * (unsigned)C::WSTAGE;
+        const int bpieces = npg * C::PPP;
+        auto issue_band = [&](int cc) {
+            char *dst = band + (cc & 1) * C::BAND_BYTES;
+#pragma unroll
+            for (int i = 0; i < C::PPP; ++i) {
+                const int pl = dw + i * C::NPROD;
+                const unsigned so = (unsigned)(cc * 4 + pl) * plane_bytes;
+#pragma unroll
+                for (int g = 0; g < C::PG; ++g)
+                    if (g < npg) bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
+            }
+        };
+        auto issue_w = [&](int s) {
+            char *dst = wring + (s % C::WS) * C::WSTAGE + dw * 1024;
+            const unsigned so = wbase + (unsigned)s * (unsigned)C::WSTAGE;
+#pragma unroll
+            for (int i = 0; i < C::WPI; ++i) bdma(rw, dst + i * (C::NPROD * 1024), wvo, so + i * (C::NPROD * 1024));
+        };
+        const __amdgpu_buffer_rsrc_t rct = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctab, 0, p.Cout * 16, 0x00020000);
+        if (!C::CTAB_IN_RING && dw == 0) bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16));   // oldest: landed before anything else
+        issue_band(0);
+#pragma unroll
+        for (int s = 0; s < C::WS - 1; ++s) issue_w(s);   // launcher: nsteps >= 6 > WS - 1
+        wait_vmcnt<(C::WS - 3) * C::WPI>();   // barrier #0 needs band(0), W(0), W(1); W(2 ..) may stay in flight
+        __builtin_amdgcn_s_barrier();
+        int cc = 0, kh = 0;
+        int prev_w = (C::WS - 4) * C::WPI;   // W / ctab pieces of the previous iteration (the prologue's W(3) with a 5-stage ring)
+        for (int s = 0; s < nsteps; ++s) {
+            int now = 0, now_w = 0;
+            if (!HAWQ_DBG_BIT(p.dbg, 1)) {
+                // after barrier #s (which closed step s - 1): ring stage (s - 1) % WS and band stage (cc + 1) & 1 are free
+                if (kh == 0 && cc + 1 < cchunks) issue_band(cc + 1), now += bpieces;
+                const int s2 = s + C::WS - 1;
+                if (s2 < nsteps) {
+                    issue_w(s2), now_w = C::WPI;
+                } else if (C::CTAB_IN_RING && s2 == nsteps && dw == 0) {
+                    bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16));
+                    now_w = 1;
+                }
+                now += now_w;
+            }
+            // Before barrier #(s + 1) this wave must have seen W(s + 2) AND the band of step s + 2 land (the MFMA waves request the first
+            // fragments of step s + 2 before barrier #(s + 2)).  LDS-DMA returns in order.  WS == 4: W(s + 2) is the last piece of the
+            // previous iteration - only this iteration's pieces may stay in flight.  WS == 5: W(s + 2) is the last piece of iteration
+            // s - 2; the band a step s + 2 = (cc', 0) needs was issued FIRST in iteration s - 1: the W pieces of s - 1 may stay too.
+            wait_vm_upto<C::BPI + 2 * C::WPI>(C::WS == 5 ? now + prev_w : now);
+            prev_w = now_w;
+            if (!HAWQ_DBG_BIT(p.dbg, 16)) __builtin_amdgcn_s_barrier();
+            if (++kh == 3) kh = 0, ++cc;
+        }
+        return;   // (the MFMA waves' epilogue barriers: ended waves are not counted by s_barrier)
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves: 64 px x 64 ch, k-half g of every slice
+    const int wave_m = wave % C::WM, g = wave / C::WM;
+    const int l31 = lane & 31, h = lane >> 5;
+    int bp0[2], yy[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int m = m0 + wave_m * 64 + q * 32 + l31;
+        m = m < p.M ? m : p.M - 1;
+        const int Gr = m / Wo, x = m - Gr * Wo;
+        bp0[q] = (Gr - G0 - 1) * Wb + x;   // band pixel of tap (kh = 0, kw = 0)
+        yy[q] = Gr % p.Ho;
+    }
+    unsigned wofs[2];   // A-fragment byte offsets inside a tap tile (swizzled rows), this group's k-half
+#pragma unroll
+    for (int c = 0; c < 2; ++c) wofs[c] = lds_off(c * 32 + cperm(l31), 2 * g + h);
+    const unsigned band_a = lds_addr(band) + (unsigned)((2 * g + h) * C::PLANE), wring_a = lds_addr(wring);
+
+    v16i acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
+
+    unsigned ap[2], wp[2];
+    auto bases = [&](int s, int cc, int kh) {
+        const unsigned bst = band_a + (unsigned)((cc & 1) * C::BAND_BYTES), wst = wring_a + (unsigned)((s % C::WS) * C::WSTAGE);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool rowok = (unsigned)(yy[q] + kh - 1) < (unsigned)p.Ho;   // else: another image's row / the padding -> zeros
+            ap[q] = bst + (unsigned)((rowok ? bp0[q] + kh * Wb : zp) * 16);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wp[c] = wst + wofs[c];
+    };
+    // three fragment buffers, one per tap of a step (fixed roles: no buffer parity across steps); the fragments of the next tap -
+    // after tap 2: tap 0 of the next step - are requested before the MFMAs of the current one
+    v4i wf[3][2], af[3][2];
+#define V2_FETCH(KW)                                                                                  \
+    if (!HAWQ_DBG_BIT(p.dbg, 4)) {                                                                    \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) wf[KW][c] = lds_read16<(KW) * C::WTAP>(wp[c]);  \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) af[KW][q] = lds_read16<(KW) * 16>(ap[q]);       \
+    }
+#define V2_MMA(KW)                                                                                    \
+    {                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) pin(wf[KW][c]);                                  \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) pin(af[KW][q]);                                  \
+        if (!HAWQ_DBG_BIT(p.dbg, 2)) {                                                                \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c)                                             \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q)                                         \
+                    acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[KW][c], af[KW][q], acc[c][q], 0, 0, 0); \
+        }                                                                                             \
+    }
+    const long long t_begin = prof ? (long long)__builtin_readcyclecounter() : 0;
+    __builtin_amdgcn_s_barrier();   // #0
+    const long long t_b0 = prof ? (long long)__builtin_readcyclecounter() : 0;
+    __builtin_amdgcn_s_setprio(2);
+    {
+        int cc = 0, kh = 0;
+        bases(0, 0, 0);
+        V2_FETCH(0)
+        for (int s = 0; s < nsteps; ++s) {
+            V2_FETCH(1) wait_lgkm<4>(); V2_MMA(0)
+            V2_FETCH(2) wait_lgkm<4>(); V2_MMA(1)
+            if (++kh == 3) kh = 0, ++cc;
+            if (s + 1 < nsteps) {   // first fragments of the next step: its operands are visible since the previous barrier
+                bases(s + 1, cc, kh);
+                V2_FETCH(0)
+                wait_lgkm<4>();
+            } else {
+                wait_lgkm<0>();
+            }
+            V2_MMA(2)
+            if (!HAWQ_DBG_BIT(p.dbg, 16)) __builtin_amdgcn_s_barrier();
+        }
+    }
+#undef V2_FETCH
+#undef V2_MMA
+    __builtin_amdgcn_s_setprio(0);
+    const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
+
+    // ---------------------------------------------------------------------- partial sums of the two k-halves meet in LDS
+    // wave (wave_m, g) keeps pixel tile q = g and hands its accumulators of pixel tile 1 - g to wave (wave_m, 1 - g)
+    v16i sum[2];
+    auto exchange = [&](auto G) {
+        constexpr int gg = decltype(G)::value;
+        char *dst = smem + (wave_m + (1 - gg) * C::WM) * C::XCH + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i v = {acc[c][1 - gg][4 * i], acc[c][1 - gg][4 * i + 1], acc[c][1 - gg][4 * i + 2], acc[c][1 - gg][4 * i + 3]};
+                *reinterpret_cast<v4i *>(dst + (c * 4 + i) * 1024) = v;
+            }
+        __syncthreads();   // MFMA waves only: the producers have ended
+        const char *src = smem + wave * C::XCH + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4i v = *reinterpret_cast<const v4i *>(src + (c * 4 + i) * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[c][4 * i + j] = acc[c][gg][4 * i + j] + v[j];
+            }
+    };
+    if (g == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
+    const long long t_xch = prof ? (long long)__builtin_readcyclecounter() : 0;
+    // ---------------------------------------------------------------------- requantisation + stores (no staging tile)
+    const int m = m0 + wave_m * 64 + g * 32 + l31;
+    const bool mok = m < p.M;
+    if constexpr (EPI == HAWQ_EPI_REQUANT) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int lch = c * 32 + h * 16;
+            int w[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                int qv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4i e = *reinterpret_cast<const v4i *>(ctab_lds + (lch + 4 * gq + j) * 16);
+                    DyNt d;
+                    d.m = e.x, d.s = e.y & 31, d.k = e.y >> 8;
+                    d.add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
+                    qv[j] = med3i(dyadic_mode<MODE>(sum[c][4 * gq + j], d), p.q_lo, p.q_hi);
+                }
+                w[gq] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+            }
+            const v4i ww = {w[0], w[1], w[2], w[3]};
+            if (mok && !HAWQ_DBG_BIT(p.dbg, 8)) {
+                char *dst = p.out_planar ? p.out + ((size_t)((c0 >> 4) + 2 * c + h) * p.M + m) * 16
+                                         : p.out + (size_t)m * p.Cout + c0 + lch;
+                *reinterpret_cast<v4i *>(dst) = ww;
+            }
+        }
+    }
+    if (prof && blockIdx.x == 8 && t == 0) {
+        p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
+        p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
+        p.dbgbuf[4] = t_b0 - t_begin, p.dbgbuf[5] = t_xch - t_loop_end;
+    }
+}
+
+using V128 = V2Cfg<2, 2, 4, 256, 3>;    // 128 px x 64 ch: 4 MFMA + 2 producer waves, 80 KiB: two workgroups per CU
+using V256 = V2Cfg<4, 4, 4, 512, 3>;    // 256 px x 64 ch: 8 MFMA + 4 producer waves, 112 KiB
+using V256S = V2Cfg<4, 4, 5, 384, 3>;   // the same for maps whose band fits 384 band pixels (14 x 14, 7 x 7): 5-stage ring, 108 KiB
+constexpr int NUM_V2 = 3;
+
+typedef void (*V2Fn)(const B2P);
+struct V2Info { V2Fn fn[2]; int bm, band_px, lds, nt; };
+#define V2_ENTRY(CFG) {{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2>}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT}
+const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V256), V2_ENTRY(V256S)};
+
+}  // namespace
+
+int band_v2_count(void) { return NUM_V2; }
+
+// [Cout][3][3][Cin] int8 -> [Cout/64][Cin/64][kh][kw][64 rows][64 B], slot s of row r at r * 64 + ((s ^ ((r >> 2) & 3)) << 4) (lds_off)
+extern "C" int hawq_pack_w3x3_band(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin) {
+    HAWQ_REQUIRE(src && dst && Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 64 == 0, "hawq_pack_w3x3_band: Cout / Cin must be positive multiples of 64");
+    const int cch = Cin >> 6;
+    for (int ct = 0; ct < (Cout >> 6); ++ct)
+        for (int cc = 0; cc < cch; ++cc)
+            for (int tap = 0; tap < 9; ++tap) {
+                int8_t *tile = dst + ((size_t)(ct * cch + cc) * 9 + tap) * 4096;
+                for (int r = 0; r < 64; ++r) {
+                    const int8_t *row = src + ((size_t)(ct * 64 + r) * 9 + tap) * Cin + cc * 64;
+                    for (int sl = 0; sl < 4; ++sl)
+                        for (int b = 0; b < 16; ++b) tile[r * 64 + ((sl ^ ((r >> 2) & 3)) << 4) + b] = row[sl * 16 + b];
+                }
+            }
+    return 0;
+}
+
+bool band_v2_applies(const hawq_conv_args *a, int v) {
+    if (v < 0 || v >= NUM_V2) return false;
+    const V2Info &vi = kV2[v];
+    const int wo = a->W, band_rows = (vi.bm + wo - 1) / wo + 1 + 2;
+    const long long M = (long long)a->N * a->H * a->W;
+    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
+           a->in_planar == 1 && a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 &&
+           a->ctab && (a->in_pitch == 0 || a->in_pitch == a->Cin) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
+           band_rows * (wo + 2) + 4 <= vi.band_px && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
+}
+
+int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream) {
+    const V2Info &vi = kV2[v];
+    B2P p;
+    p.in = (const char *)a->in, p.wgt = (const char *)a->wgt_band, p.ctab = a->ctab, p.out = (char *)a->out_q;
+    p.res_in = (const char *)a->res_in, p.res_out = (char *)a->res_out, p.flags = a->flags;
+    p.M = a->N * a->H * a->W, p.rows_total = a->N * a->H, p.Ho = a->H, p.Wo = a->W, p.Cin = a->Cin, p.Cout = a->Cout;
+    p.cchunks = a->Cin >> 6, p.nsteps = 3 * p.cchunks;
+    p.out_planar = a->out_planar;
+    p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
+    p.mq = a->mq, p.eq = a->eq, p.m_id = a->m_id_scalar, p.e_id = a->e_id_scalar;
+    p.in_bytes = (unsigned)((long long)p.M * a->Cin), p.wgt_bytes = (unsigned)((long long)a->Cout * a->Cin * 9);
+    p.dbg = dbg;
+    static long long *dbg_dev = nullptr;
+    if (HAWQ_DBG_BIT(dbg, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 8 * sizeof(long long));
+    p.dbgbuf = HAWQ_DBG_BIT(dbg, 128) ? dbg_dev : nullptr;
+    static const bool attrs = [] {
+        bool good = true;
+        for (const V2Info &i : kV2)
+            for (int k = 0; k < 2; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+        return good;
+    }();
+    HAWQ_REQUIRE(attrs, "hawq_conv2d: hipFuncSetAttribute failed for the round-5 3x3 kernels");
+    const int grid = ((p.M + vi.bm - 1) / vi.bm) * (p.Cout >> 6);
+    hipLaunchKernelGGL(vi.fn[exact_tie ? 1 : 0], dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
+    HAWQ_CHECK_HIP(hipGetLastError());
+    if (p.dbgbuf) {   // experiment hook (synchronises!)
+        long long hb[6];
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipMemcpy(hb, p.dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[band-v2 bm=%d M=%d Cin=%d Cout=%d grid=%d lds=%d] steps %lld: prologue %lld | K loop %lld | epilogue %lld cycles (wave 0 of workgroup 8); wait at barrier 0 %lld, exchange %lld\n",
+                vi.bm, p.M, p.Cin, p.Cout, grid, vi.lds, hb[3], hb[0], hb[1], hb[2], hb[4], hb[5]);
+    }
+    return 0;
+}

@@ -1447,8 +1447,21 @@ int pick_tile(int M, int Cout, bool dual) {
 bool band_persist_applies(const hawq_conv_args *a);
 int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs_per_cu, void *stream);
 
-extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES + 2; }  // the 3x3 band kernels are the last ids
+// band_v2.hip: the round-5 3x3 kernels (ids after the weight-stationary kernel's two)
+int band_v2_count(void);
+bool band_v2_applies(const hawq_conv_args *a, int v);
+int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream);
+
+extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count(); }  // the 3x3 kernels are the last ids
 extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES + 2; }  // + the weight-stationary kernel of band_persist.hip with 1 / 2 workgroups per CU
+
+extern "C" int hawq_conv2d_num_band2_tiles(void) { return band_v2_count(); }
+extern "C" int hawq_conv2d_band2_tile(const hawq_conv_args *a) {
+    if (!a || a->W <= 0 || a->H <= 0 || a->Cin <= 0 || a->Cout <= 0) return 0;
+    for (int v = 0; v < band_v2_count(); ++v)
+        if (band_v2_applies(a, v)) return NUM_TILES + NUM_BAND_TILES + 2 + v + 1;
+    return 0;
+}
 
 extern "C" int hawq_conv2d_band_tile(const hawq_conv_args *a) {
     if (!a || a->W <= 0 || a->H <= 0 || a->Cin <= 0 || a->Cout <= 0) return 0;
@@ -1601,6 +1614,11 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         for (int k = 0; k < NUM_BAND_TILES && tile < 0; ++k)
             if (band_applies(kBand[kBandPreference[k]], a)) tile = NUM_TILES + kBandPreference[k];
         HAWQ_REQUIRE(tile >= 0, "hawq_conv2d: in_planar input but no 3x3 band kernel takes this layer");
+    }
+    if (tile >= NUM_TILES + NUM_BAND_TILES + 2 && tile < NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count()) {
+        const int v = tile - (NUM_TILES + NUM_BAND_TILES + 2);
+        HAWQ_REQUIRE(band_v2_applies(a, v), "hawq_conv2d: tile %d (round-5 3x3 kernel) does not apply to this layer", a->tile);
+        return band_v2_launch(a, v, p.k0 == 2, p.dbg, stream);
     }
     if (tile == NUM_TILES + NUM_BAND_TILES || tile == NUM_TILES + NUM_BAND_TILES + 1) {
         HAWQ_REQUIRE(band_persist_applies(a), "hawq_conv2d: tile %d (weight-stationary 3x3 kernel) does not apply to this layer", a->tile);

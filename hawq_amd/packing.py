@@ -46,6 +46,21 @@ def pack_conv_weight(w_int: np.ndarray, w_bits: int, cin_pad: int | None = None,
     return pack_hawq4(out).reshape(-1)
 
 
+def pack_w3x3_band(w_packed: np.ndarray, cout: int, cin: int) -> np.ndarray:
+    """[Cout][3][3][Cin] int8 bytes (pack_conv_weight's layout) -> the stream the round-5 3x3 kernels consume
+    (include/hawq_mi355.h: hawq_conv_args.wgt_band): [Cout/64][Cin/64][kh][kw][64 rows][64 B], the four 16-byte slots of
+    row r stored at slot ^ ((r >> 2) & 3) - every weight-ring LDS-DMA instruction then copies one contiguous KiB and the tile
+    arrives in LDS already in the bank-conflict-free order the MFMA fragment reads expect.  Same integers, only re-ordered
+    (the C twin is hawq_pack_w3x3_band)."""
+    assert cout % 64 == 0 and cin % 64 == 0
+    w = np.asarray(w_packed, np.uint8).reshape(cout // 64, 64, 9, cin // 64, 4, 16)      # ct, r, tap, cc, slot, byte
+    r = np.arange(64)
+    src_slot = np.arange(4)[None, :] ^ ((r[:, None] >> 2) & 3)                           # stored slot s holds logical slot s ^ sw(r)
+    w = w[:, r[:, None], :, :, src_slot, :]                                             # -> r, s, ct, tap, cc, byte
+    w = w.transpose(2, 4, 3, 0, 1, 5)                                                    # ct, cc, tap, r, s, byte
+    return np.ascontiguousarray(w).reshape(-1)
+
+
 def pack_stem_weight(w_int: np.ndarray) -> np.ndarray:
     """[64][3][7][7] integer stem weights -> [64][7][8][4] int8 (kw and c zero padded)."""
     w = np.rint(np.asarray(w_int, np.float64)).astype(np.int64)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HAWQ_ABI_VERSION 4
+#define HAWQ_ABI_VERSION 5
 
 const char *hawq_last_error(void);
 int hawq_abi_version(void);
@@ -140,6 +140,11 @@ typedef struct hawq_conv_args {
                   at all; on the general path channels in [n_valid, out_pitch) are written as zeros.  Multiple of 16,
                   REQUANT / RESIDUAL epilogues with NHWC rows (fast REQUANT, or the general path), single branch.           */
     int32_t in_pitch, out_pitch;
+    /* ABI 5 - the round-5 3x3 kernels (band_v2.hip; 3x3 / stride 1 / pad 1, int8 operands, Cin >= 128, planar input): the SAME weight
+       integers as `wgt` (quant_modules.py:462-466: weight_integer of the BN-folded conv), packed by hawq_pack_w3x3_band into the byte
+       stream a workgroup consumes - [Cout/64][Cin/64][kh][kw][64 rows][64 B], the 16-byte slots of a row XOR-swizzled - so that every
+       LDS-DMA instruction of the weight ring copies one contiguous KiB.  NULL = not provided: those tile ids refuse the layer. */
+    const void *wgt_band;
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
@@ -151,6 +156,13 @@ int hawq_conv2d_num_band_tiles(void);
 /* 1-based id of the preferred band tile that takes this layer as described (geometry, widths, epilogue,
  * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */
 int hawq_conv2d_band_tile(const hawq_conv_args *args);
+/* ABI 5: the hawq_conv2d_num_band2_tiles() tile ids AFTER the ones above are the round-5 3x3 kernels (need args->wgt_band and
+ * in_planar == 1).  hawq_conv2d_band2_tile: 1-based id of the first of them that takes the layer as described, else 0.
+ * hawq_pack_w3x3_band: [Cout][3][3][Cin] int8 (the layout of `wgt`) -> the stream described at hawq_conv_args.wgt_band, on the host
+ * (dst and src are host pointers of Cout * 9 * Cin bytes; Cin and Cout multiples of 64). */
+int hawq_conv2d_num_band2_tiles(void);
+int hawq_conv2d_band2_tile(const hawq_conv_args *args);
+int hawq_pack_w3x3_band(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin);
 
 /* Fused launch of two consecutive layers of the bottleneck graph (q_resnet.py:231-260): the 1x1 expand conv of unit i
  * with its RESIDUAL epilogue (x + identity -> quant_act_int32 -> ReLU -> quant_act of unit i+1) and the 1x1 reduce

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_lib.SIGNATURES) | {"hawq_last_error"} == declared
-    assert lib.hawq_abi_version() == 4
+    assert lib.hawq_abi_version() == 5
     assert ctypes.sizeof(_lib.ConvArgs) % 8 == 0
 
 
