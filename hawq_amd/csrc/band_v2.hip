@@ -59,13 +59,17 @@ struct V2Cfg {
     // the 128-pixel tile must fit 80 KiB twice per CU: its requant constants land in the first ring stage the K loop releases for
     // good; the larger tiles have the CU to themselves and own a KiB for them
     static constexpr bool CTAB_IN_RING = WM == 2;
-    static constexpr int LDS_BYTES = RING_END + (CTAB_IN_RING ? 0 : 1024);
+    // 64 bytes of synchronisation words (landed[4], done[8]): behind the constants - or, for the 80 KiB tile, the last four pixels
+    // of plane 3 of band stage 1, which no tap reads (launcher: zp + 4 <= BAND_PX - 4) and whose four lanes the band fill masks off
+    // (an LDS-DMA writes nothing for lanes EXEC has switched off: tools/ubench/dma_exec.hip)
+    static constexpr int OFF_SYNC = CTAB_IN_RING ? 2 * BAND_BYTES - 64 : RING_END + 1024;
+    static constexpr int LDS_BYTES = RING_END + (CTAB_IN_RING ? 0 : 1024 + 64);
     static constexpr int PG = BAND_PX / 64;             // 64-pixel groups per plane
     static constexpr int PPP = 4 / NPROD;               // planes per producer wave
     static constexpr int BPI = PG * PPP, WPI = 12 / NPROD;
     static constexpr int XCH = 8192;                    // exchange area per MFMA wave: 32 registers x 64 lanes x 4 B
     static_assert(NPROD == 2 || NPROD == 4, "producer waves");
-    static_assert(BAND_PX % 64 == 0 && WS >= 4 && WS <= 5, "ring");
+    static_assert(BAND_PX % 64 == 0 && WS >= 4 && WS <= 6, "ring");
     static_assert(NW * XCH <= (CTAB_IN_RING ? 2 * BAND_BYTES : RING_END), "the partial-sum exchange reuses the band area (and the ring)");
 };
 
@@ -81,6 +85,23 @@ __device__ __forceinline__ void wait_vm_upto(int n) {   // s_waitcnt vmcnt(n) fo
         if (n >= N) wait_vmcnt<N>(); else wait_vm_upto<N - 1>(n);
     }
 }
+
+// ---- flag synchronisation (round 5): no workgroup barrier inside the K loop.  The probe build showed a K loop of MFMAs alone at ~89 %
+// of the matrix pipe and the same loop with one s_barrier per step at 66 % (profiles/r05_band_v2.md): twelve waves that meet 12-24 times
+// per tile wait for the slowest every time, and the two MFMA waves of a SIMD restart in lock step.  Instead
+//   landed[p] (producer wave p): number of steps whose operands - this producer's share - are in LDS; written after the covering vmcnt wait
+//   done[w]   (MFMA wave w)    : number of steps whose fragment reads have all returned
+// live in LDS.  An MFMA wave reads landed[] ahead of time (one broadcast ds_read_b128 per step, covered by the fragment waits) and only
+// spins when data is really late; a producer refills ring stage (i - 1) % WS once min(done[]) >= i.  LDS serves the DS instructions of a
+// CU in order and an LDS-DMA piece is in LDS when its wave's vmcnt says so, hence flag-after-data on the writer's side and
+// data-after-flag on the reader's side is all the ordering there is.
+__device__ __forceinline__ int min4(const v4i &v) { return min(min(v.x, v.y), min(v.z, v.w)); }
+__device__ __forceinline__ int lds_min4_now(unsigned addr) {   // min of the 4 dwords at a wave-uniform LDS address, as a scalar
+    v4i v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(min4(v));
+}
+__device__ __forceinline__ void lds_store_b32(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
 // EPI: HAWQ_EPI_REQUANT, or HAWQ_EPI_RESIDUAL (single branch, uint16 residuals: the second conv of a basic block).
 // MODE: 0 = tie-free tables, 2 = exact-tie correction on every requant (fast_tables bit 2).
@@ -109,6 +130,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     const int nsteps = p.nsteps, cchunks = p.cchunks;
     char *const band = smem, *const wring = smem + C::OFF_W;
     char *const ctab_lds = C::CTAB_IN_RING ? wring + (nsteps % C::WS) * C::WSTAGE : smem + C::RING_END;
+    const unsigned sync_a = lds_addr(smem + C::OFF_SYNC);   // landed[4] at +0, done[8] at +16
+    if (t < 16) {
+        const bool used = t < 4 ? t < C::NPROD : (t - 4 < C::NW || t >= 12);
+        *reinterpret_cast<int *>(smem + C::OFF_SYNC + t * 4) = used ? 0 : 0x7fffffff;
+    }
+    __syncthreads();
 
     if (wave >= C::NW) {
         // ------------------------------------------------------------------ producer waves: every LDS-DMA of the kernel
@@ -127,8 +154,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         const unsigned wvo = (unsigned)(dw * 1024 + lane * 16);
         const unsigned plane_bytes = (unsigned)p.M * 16u;
         const unsigned wbase = (unsigned)tc * (unsigned)nsteps * (unsigned)C::WSTAGE;
-        const int bpieces = npg * C::PPP;
-        auto issue_band = [&](int cc) {
+        auto issue_band = [&](int cc) {   // returns the pieces issued
             char *dst = band + (cc & 1) * C::BAND_BYTES;
 #pragma unroll
             for (int i = 0; i < C::PPP; ++i) {
@@ -136,8 +162,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
                 const unsigned so = (unsigned)(cc * 4 + pl) * plane_bytes;
 #pragma unroll
                 for (int g = 0; g < C::PG; ++g)
-                    if (g < npg) bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
+                    if (g < npg) {
+                        if (C::CTAB_IN_RING && pl == 3 && g == C::PG - 1 && (cc & 1)) {   // the synchronisation words live in these four pixels
+                            if (lane < 60) bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
+                        } else {
+                            bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
+                        }
+                    }
             }
+            return npg * C::PPP;
         };
         auto issue_w = [&](int s) {
             char *dst = wring + (s % C::WS) * C::WSTAGE + dw * 1024;
@@ -145,39 +178,50 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
 #pragma unroll
             for (int i = 0; i < C::WPI; ++i) bdma(rw, dst + i * (C::NPROD * 1024), wvo, so + i * (C::NPROD * 1024));
         };
+        auto publish = [&](int n) { lds_store_b32(sync_a + (unsigned)(dw * 4), n); };
+        auto wait_done = [&](int n) {   // every MFMA wave has finished the fragment reads of steps < n
+            while (true) {
+                const int a = lds_min4_now(sync_a + 16), b = C::NW > 4 ? lds_min4_now(sync_a + 32) : 0x7fffffff;
+                if (min(a, b) >= n) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        };
         const __amdgpu_buffer_rsrc_t rct = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctab, 0, p.Cout * 16, 0x00020000);
         if (!C::CTAB_IN_RING && dw == 0) bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16));   // oldest: landed before anything else
         issue_band(0);
 #pragma unroll
         for (int s = 0; s < C::WS - 1; ++s) issue_w(s);   // launcher: nsteps >= 6 > WS - 1
-        wait_vmcnt<(C::WS - 3) * C::WPI>();   // barrier #0 needs band(0), W(0), W(1); W(2 ..) may stay in flight
-        __builtin_amdgcn_s_barrier();
+        wait_vmcnt<(C::WS - 2) * C::WPI>();   // band(0), W(0)
+        publish(1);
         int cc = 0, kh = 0;
-        int prev_w = (C::WS - 4) * C::WPI;   // W / ctab pieces of the previous iteration (the prologue's W(3) with a 5-stage ring)
-        for (int s = 0; s < nsteps; ++s) {
-            int now = 0, now_w = 0;
-            if (!HAWQ_DBG_BIT(p.dbg, 1)) {
-                // after barrier #s (which closed step s - 1): ring stage (s - 1) % WS and band stage (cc + 1) & 1 are free
-                if (kh == 0 && cc + 1 < cchunks) issue_band(cc + 1), now += bpieces;
-                const int s2 = s + C::WS - 1;
-                if (s2 < nsteps) {
-                    issue_w(s2), now_w = C::WPI;
-                } else if (C::CTAB_IN_RING && s2 == nsteps && dw == 0) {
-                    bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16));
-                    now_w = 1;
-                }
-                now += now_w;
+        // pieces (band, W) this wave issued in the last three iterations; the prologue's W(2 ..) count as iterations -1, -2, ...
+        int hb1 = 0, hw1 = C::WPI, hb2 = 0, hw2 = C::WS >= 5 ? C::WPI : 0, hb3 = 0, hw3 = C::WS >= 6 ? C::WPI : 0;
+        for (int i = 0; i < nsteps; ++i) {
+            // (1) W(i + 1) - the last piece of iteration i + 2 - WS - has landed once at most the pieces of the WS - 3 iterations after it
+            //     are in flight (LDS-DMA returns in order).  If step i + 1 opens a slice, its band was the FIRST thing iteration i - 2
+            //     issued: then only the pieces behind it may stay
+            int allow = hb1 + hw1;
+            if (C::WS >= 5) allow += hb2 + hw2;
+            if (C::WS >= 6) allow += hb3 + hw3;
+            if (kh == 2) allow = min(allow, hw2 + hb1 + hw1);
+            wait_vm_upto<3 * (C::BPI + C::WPI)>(allow);
+            publish(i + 2);
+            // (2) refill: ring stage (i - 1) % WS and band stage (cc + 1) & 1 are free once every MFMA wave is done with step i - 1
+            int nb = 0, nw = 0;
+            const int s2 = i + C::WS - 1;
+            const bool wantb = kh == 0 && cc + 1 < cchunks, wantw = s2 < nsteps, wantc = C::CTAB_IN_RING && s2 == nsteps && dw == 0;
+            if ((wantb || wantw || wantc) && !HAWQ_DBG_BIT(p.dbg, 1)) {
+                wait_done(i);
+                if (wantb) nb = issue_band(cc + 1);
+                if (wantw) issue_w(s2), nw = C::WPI;
+                if (wantc) bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16)), nw = 1;
             }
-            // Before barrier #(s + 1) this wave must have seen W(s + 2) AND the band of step s + 2 land (the MFMA waves request the first
-            // fragments of step s + 2 before barrier #(s + 2)).  LDS-DMA returns in order.  WS == 4: W(s + 2) is the last piece of the
-            // previous iteration - only this iteration's pieces may stay in flight.  WS == 5: W(s + 2) is the last piece of iteration
-            // s - 2; the band a step s + 2 = (cc', 0) needs was issued FIRST in iteration s - 1: the W pieces of s - 1 may stay too.
-            wait_vm_upto<C::BPI + 2 * C::WPI>(C::WS == 5 ? now + prev_w : now);
-            prev_w = now_w;
-            if (!HAWQ_DBG_BIT(p.dbg, 16)) __builtin_amdgcn_s_barrier();
+            hb3 = hb2, hw3 = hw2, hb2 = hb1, hw2 = hw1, hb1 = nb, hw1 = nw;
             if (++kh == 3) kh = 0, ++cc;
         }
-        return;   // (the MFMA waves' epilogue barriers: ended waves are not counted by s_barrier)
+        wait_vmcnt<0>();
+        publish(nsteps + 2);   // everything (the constants too) has landed; this wave touches the synchronisation words no more
+        return;                // (the MFMA waves' epilogue barriers: ended waves are not counted by s_barrier)
     }
 
     // ---------------------------------------------------------------------- MFMA waves: 64 px x 64 ch, k-half g of every slice
@@ -235,7 +279,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         }                                                                                             \
     }
     const long long t_begin = prof ? (long long)__builtin_readcyclecounter() : 0;
-    __builtin_amdgcn_s_barrier();   // #0
+    const unsigned done_a = sync_a + 16u + (unsigned)(wave * 4);
+    v4i pl;   // landed[] as requested at the top of a step
+    auto ensure = [&](int n) {   // every producer's landed[] >= n; `pl` is covered by a fragment wait, the slow path spins
+        pin(pl);
+        if (__builtin_amdgcn_readfirstlane(min4(pl)) >= n) return;
+        while (lds_min4_now(sync_a) < n) __builtin_amdgcn_s_sleep(1);
+    };
+    while (lds_min4_now(sync_a) < 1) __builtin_amdgcn_s_sleep(1);   // band(0), W(0)
     const long long t_b0 = prof ? (long long)__builtin_readcyclecounter() : 0;
     __builtin_amdgcn_s_setprio(2);
     {
@@ -243,18 +294,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         bases(0, 0, 0);
         V2_FETCH(0)
         for (int s = 0; s < nsteps; ++s) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(sync_a) : "memory");   // for the prefetch at the end of this step
             V2_FETCH(1) wait_lgkm<4>(); V2_MMA(0)
             V2_FETCH(2) wait_lgkm<4>(); V2_MMA(1)
             if (++kh == 3) kh = 0, ++cc;
-            if (s + 1 < nsteps) {   // first fragments of the next step: its operands are visible since the previous barrier
+            if (s + 1 < nsteps) {   // first fragments of the next step
+                ensure(s + 2);
                 bases(s + 1, cc, kh);
                 V2_FETCH(0)
                 wait_lgkm<4>();
             } else {
                 wait_lgkm<0>();
             }
+            lds_store_b32(done_a, s + 1);   // every fragment read of step s has returned: its ring stage (and, after kh == 2, its band) is free
             V2_MMA(2)
-            if (!HAWQ_DBG_BIT(p.dbg, 16)) __builtin_amdgcn_s_barrier();
         }
     }
 #undef V2_FETCH
@@ -262,6 +315,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     __builtin_amdgcn_s_setprio(0);
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
 
+    while (lds_min4_now(sync_a) < nsteps + 2) __builtin_amdgcn_s_sleep(1);   // the producers are through (requant constants landed)
+    __syncthreads();   // MFMA waves only (ended waves do not count): every wave is done with band and ring, which the exchange reuses
     // ---------------------------------------------------------------------- partial sums of the two k-halves meet in LDS
     // wave (wave_m, g) keeps pixel tile q = g and hands its accumulators of pixel tile 1 - g to wave (wave_m, 1 - g)
     v16i sum[2];
@@ -363,7 +418,7 @@ bool band_v2_applies(const hawq_conv_args *a, int v) {
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
            a->in_planar == 1 && a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 &&
            a->ctab && (a->in_pitch == 0 || a->in_pitch == a->Cin) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
-           band_rows * (wo + 2) + 4 <= vi.band_px && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
+           band_rows * (wo + 2) + 8 <= vi.band_px && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
 }
 
 int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream) {
