@@ -1,28 +1,33 @@
 // Round 5: 3x3 / stride 1 / pad 1 convolution (QuantBnConv2d + ReLU + QuantAct, quant_modules.py:489-494, 527-545, 233-260; the
 // second conv of every ResNet50 bottleneck, q_resnet.py:241-243, and both convs of a ResNet18/34 basic block, :300-306) rebuilt
-// around what tools/ubench/dma_issue.hip measured on gfx950 (profiles/r05_ubench_dma_issue.txt):
+// around what this round measured on gfx950 (profiles/r05_band_v2.md, tools/ubench/dma_issue.hip, dma_exec.hip):
 //   * an LDS-DMA instruction costs the CU's vector-memory path ~2 cycles per 128-byte LINE it touches (min 16 per KiB): sixteen
 //     64-byte row segments a filter row apart - the shape every weight tile had so far - cap a CU at 28-32 B/clk, a contiguous
-//     KiB runs at 56-64 B/clk;
-//   * ONE wave that issues its pieces back to back ingests 45-65 GB/s; rounds 1-4 believed a wave was capped at 6-10 GB/s (the
-//     probe that said so divided 64-bit integers per issue) and spent 4-8 producer waves per workgroup on it.
+//     KiB runs at 56-64 B/clk; and ONE wave that issues its pieces back to back ingests 45-65 GB/s (rounds 1-4 believed a wave
+//     was capped at 6-10 GB/s - the probe that said so divided 64-bit integers per issue - and spent 4-8 producer waves on it);
+//   * a K loop of MFMAs alone keeps the matrix pipe ~89 % busy, the same loop with one s_barrier per step 66 %: twelve waves that
+//     meet 12-24 times per tile wait for the slowest every time;
+//   * once the barriers are gone the loop is bound by LDS bandwidth: 64 px x 64 ch wave tiles read one 1-KiB fragment per MFMA
+//     (50 % of the LDS cycles before bank conflicts and the DMA's own writes), and a band with zero columns (row pitch Wo + 2)
+//     cannot be read conflict-free at all on 14 x 14 / 7 x 7 maps (16 lanes of a ds_read_b128 group, 14 distinct bank groups).
 // Therefore:
 //   * weights are packed on the host into the exact byte stream a workgroup consumes: [Cout/64][slice][kh][kw][64 rows][64 B],
 //     rows pre-swizzled for conflict-free fragment reads, so a filter-row step is 12 contiguous KiB (hawq_pack_w3x3_band);
-//   * activations arrive as channel-group planes (hawq_conv_args.in_planar), 64 pixels of a plane = one contiguous KiB;
-//     `buffer_load ... lds` with a per-lane 32-bit offset: lanes of the zero columns / rows outside the tensor point beyond
-//     num_records and the hardware writes zeros (no zero page, no 64-bit address arithmetic);
-//   * 2-4 producer waves instead of 8 leave the register file to the MFMA waves: 3 waves per SIMD at <= 168 registers;
-//   * every MFMA wave owns a 64 px x 64 ch accumulator tile (2 x 2 MFMA tiles: ONE ds_read_b128 per MFMA; the 64 px x 32 ch
-//     wave tiles of the round-3 small tiles needed 1.5 and were LDS-bound) and the waves of a workgroup split K between them:
-//     wave group g takes k-half g (channels 32g .. 32g+31 of every 64-channel slice), so a 128-pixel tile still has 4 MFMA
-//     waves and a 256-pixel tile 8.  The two partial accumulator sets meet once, after the K loop, through LDS, each wave
-//     keeping one 32-pixel half - which also halves the requantisation work per wave;
+//   * activations arrive as channel-group planes (hawq_conv_args.in_planar) and the band is DENSE: band pixel j is global pixel
+//     mb0 + j, a tap is a constant pixel offset (kh - 1) * Wo + (kw - 1), lanes whose tap falls outside their image row / column
+//     read one shared zero word instead (9 validity bits per lane, one v_cndmask per fragment address).  Consecutive lanes read
+//     consecutive 16-byte units: conflict-free on every map size, every band piece is a contiguous, line-aligned KiB
+//     (`buffer_load ... lds`: pixels before / behind the tensor are out of range and the hardware writes zeros), and the band is
+//     a quarter smaller;
+//   * 2-4 producer waves own every LDS-DMA; no workgroup barrier inside the K loop: landed[] / done[] counters in LDS (below);
+//   * an MFMA wave owns PT x 2 MFMA tiles (PT = 4: 128 px x 64 ch, 128 accumulators, 0.75 fragment reads per MFMA; PT = 2:
+//     64 px x 64 ch) and the waves of a workgroup split K: wave group g takes k-half g (channels 32g .. 32g+31 of every
+//     64-channel slice).  The two partial accumulator sets meet once, after the K loop, through LDS, each wave keeping half of
+//     its pixel tiles - which also halves the requantisation work per wave;
 //   * the epilogue needs no staging tile: a lane holds 16 consecutive channels of one pixel = one 16-byte store (NHWC rows)
 //     or 32 lanes x 16 B = 512 contiguous bytes (planes).
-// Steps, ring and barriers follow conv3x3_band_kernel (conv_igemm.hip): one step = one filter row of one 64-channel slice
-// (3 taps), W ring of WS stages issued WS - 1 steps ahead, band double-buffered per slice, one s_barrier per step, the first
-// fragments of step s + 1 requested before the barrier that closes step s.
+// One step = one filter row of one 64-channel slice (3 taps, 12 KiB of weights); W ring of WS stages, band double-buffered
+// per slice.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -40,7 +45,7 @@ struct B2P {
     const char *res_in;    // RESIDUAL: [M][Cout] uint16
     char *res_out;         // RESIDUAL: [M][Cout] uint16 or null
     int *flags;
-    int M, rows_total, Ho, Wo, Cin, Cout;
+    int M, Ho, Wo, Cin, Cout;
     int nsteps, cchunks;
     int out_planar, q_lo, q_hi;
     int mq, eq, m_id, e_id;
@@ -49,28 +54,30 @@ struct B2P {
     long long *dbgbuf;
 };
 
-template <int WM_, int NPROD_, int WS_, int BAND_PX_, int MINW_>
+template <int PT_, int WM_, int NPROD_, int WS_, int BAND_PX_, int MINW_>
 struct V2Cfg {
-    static constexpr int WM = WM_, NPROD = NPROD_, WS = WS_, BAND_PX = BAND_PX_, MINW = MINW_;   // MINW: waves per SIMD the register budget is cut for
-    static constexpr int BM = 64 * WM, NW = 2 * WM, NT = (NW + NPROD) * 64;
+    static constexpr int PT = PT_, WM = WM_, NPROD = NPROD_, WS = WS_, BAND_PX = BAND_PX_, MINW = MINW_;   // MINW: waves per SIMD the register budget is cut for
+    static constexpr int BM = 32 * PT * WM, NW = 2 * WM, NT = (NW + NPROD) * 64;
     static constexpr int PLANE = BAND_PX * 16, BAND_BYTES = 4 * PLANE;
     static constexpr int WTAP = 4096, WSTAGE = 3 * WTAP;
     static constexpr int OFF_W = 2 * BAND_BYTES, RING_END = OFF_W + WS * WSTAGE;
-    // the 128-pixel tile must fit 80 KiB twice per CU: its requant constants land in the first ring stage the K loop releases for
-    // good; the larger tiles have the CU to themselves and own a KiB for them
-    static constexpr bool CTAB_IN_RING = WM == 2;
-    // 64 bytes of synchronisation words (landed[4], done[8]): behind the constants - or, for the 80 KiB tile, the last four pixels
-    // of plane 3 of band stage 1, which no tap reads (launcher: zp + 4 <= BAND_PX - 4) and whose four lanes the band fill masks off
-    // (an LDS-DMA writes nothing for lanes EXEC has switched off: tools/ubench/dma_exec.hip)
-    static constexpr int OFF_SYNC = CTAB_IN_RING ? 2 * BAND_BYTES - 64 : RING_END + 1024;
-    static constexpr int LDS_BYTES = RING_END + (CTAB_IN_RING ? 0 : 1024 + 64);
+    // A tile that must fit 80 KiB twice per CU has no byte to spare: its requant constants land in the first ring stage the K loop
+    // releases for good, and its 64 bytes of synchronisation words are the last four pixels of plane 3 of band stage 1, which no tap
+    // reads (launcher: band length <= BAND_PX - 4) and whose four lanes the band fill masks off (an LDS-DMA writes nothing for lanes
+    // EXEC has switched off: tools/ubench/dma_exec.hip).  The larger tiles have the CU to themselves and own 1 KiB + 64 B for them.
+    static constexpr bool TIGHT = RING_END == 80 * 1024;
+    static constexpr int OFF_CTAB = RING_END, OFF_SYNC = TIGHT ? 2 * BAND_BYTES - 64 : RING_END + 1024;
+    static constexpr int LDS_BYTES = RING_END + (TIGHT ? 0 : 1024 + 64);
     static constexpr int PG = BAND_PX / 64;             // 64-pixel groups per plane
     static constexpr int PPP = 4 / NPROD;               // planes per producer wave
     static constexpr int BPI = PG * PPP, WPI = 12 / NPROD;
-    static constexpr int XCH = 8192;                    // exchange area per MFMA wave: 32 registers x 64 lanes x 4 B
+    static constexpr int HQ = PT / 2;                   // pixel tiles a wave keeps after the exchange
+    static constexpr int XCH = HQ * 2 * 16 * 256;       // exchange area per MFMA wave: HQ x 2 tiles x 16 registers x 64 lanes x 4 B
+    static_assert(PT == 2 || PT == 4, "pixel tiles per MFMA wave");
     static_assert(NPROD == 2 || NPROD == 4, "producer waves");
     static_assert(BAND_PX % 64 == 0 && WS >= 4 && WS <= 6, "ring");
-    static_assert(NW * XCH <= (CTAB_IN_RING ? 2 * BAND_BYTES : RING_END), "the partial-sum exchange reuses the band area (and the ring)");
+    static_assert(NW * XCH <= (TIGHT ? 2 * BAND_BYTES : RING_END), "the partial-sum exchange reuses the band area (and the ring)");
+    static_assert(3 * (BPI + WPI) <= 60, "vmcnt is a 6-bit counter");
 };
 
 __device__ __forceinline__ void bdma(__amdgpu_buffer_rsrc_t r, char *lds, unsigned voff, unsigned soff) {
@@ -86,9 +93,7 @@ __device__ __forceinline__ void wait_vm_upto(int n) {   // s_waitcnt vmcnt(n) fo
     }
 }
 
-// ---- flag synchronisation (round 5): no workgroup barrier inside the K loop.  The probe build showed a K loop of MFMAs alone at ~89 %
-// of the matrix pipe and the same loop with one s_barrier per step at 66 % (profiles/r05_band_v2.md): twelve waves that meet 12-24 times
-// per tile wait for the slowest every time, and the two MFMA waves of a SIMD restart in lock step.  Instead
+// ---- flag synchronisation: no workgroup barrier inside the K loop.
 //   landed[p] (producer wave p): number of steps whose operands - this producer's share - are in LDS; written after the covering vmcnt wait
 //   done[w]   (MFMA wave w)    : number of steps whose fragment reads have all returned
 // live in LDS.  An MFMA wave reads landed[] ahead of time (one broadcast ds_read_b128 per step, covered by the fragment waits) and only
@@ -121,35 +126,26 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     const int m0 = tm * C::BM, c0 = tc << 6;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: role and k-half branches are scalar branches
-    const int Wo = p.Wo, Wb = Wo + 2;
-    const int G0 = m0 / Wo - 1;   // global row (n * Ho + y) held by band row 0
+    const int Wo = p.Wo;
+    const int mb0 = (m0 - Wo - 1) & ~7;                                  // global pixel held by band pixel 0 (line-aligned; may be negative)
     const int mlast = (m0 + C::BM < p.M ? m0 + C::BM : p.M) - 1;
-    const int brows = mlast / Wo - G0 + 2;   // band rows the tile's pixels touch (their own rows + one halo row each side)
-    const int zp = brows * Wb;               // band pixels zp .. zp + 3 of every plane are zeros (launcher: zp + 4 <= BAND_PX)
-    const int npg = (zp + 4 + 63) >> 6;      // 64-pixel groups of a plane that are filled at all
+    const int npg = (mlast + Wo + 1 - mb0 + 64) >> 6;                    // 64-pixel groups of a plane that are filled at all
     const int nsteps = p.nsteps, cchunks = p.cchunks;
     char *const band = smem, *const wring = smem + C::OFF_W;
-    char *const ctab_lds = C::CTAB_IN_RING ? wring + (nsteps % C::WS) * C::WSTAGE : smem + C::RING_END;
-    const unsigned sync_a = lds_addr(smem + C::OFF_SYNC);   // landed[4] at +0, done[8] at +16
-    if (t < 16) {
-        const bool used = t < 4 ? t < C::NPROD : (t - 4 < C::NW || t >= 12);
-        *reinterpret_cast<int *>(smem + C::OFF_SYNC + t * 4) = used ? 0 : 0x7fffffff;
-    }
-    __syncthreads();
+    char *const ctab_lds = C::TIGHT ? wring + (nsteps % C::WS) * C::WSTAGE : smem + C::OFF_CTAB;
+    const unsigned sync_a = lds_addr(smem + C::OFF_SYNC);   // landed[4] at +0, done[8] at +16, 16 zero bytes at +48
 
     if (wave >= C::NW) {
         // ------------------------------------------------------------------ producer waves: every LDS-DMA of the kernel
         const int dw = wave - C::NW;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)p.in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, (int)p.wgt_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rct = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctab, 0, p.Cout * 16, 0x00020000);
         unsigned bvo[C::PG];   // byte offset of this lane's pixel inside a plane, or out of range (the hardware then writes zeros)
 #pragma unroll
         for (int g = 0; g < C::PG; ++g) {
-            const int bpx = g * 64 + lane;
-            const int br = bpx / Wb, bc = bpx - br * Wb;
-            const int G = G0 + br, x = bc - 1;
-            const bool v = (unsigned)G < (unsigned)p.rows_total && (unsigned)x < (unsigned)Wo && br < brows;
-            bvo[g] = v ? (unsigned)(G * Wo + x) * 16u : 0x80000000u;
+            const int pix = mb0 + g * 64 + lane;
+            bvo[g] = (unsigned)pix < (unsigned)p.M ? (unsigned)pix * 16u : 0x80000000u;
         }
         const unsigned wvo = (unsigned)(dw * 1024 + lane * 16);
         const unsigned plane_bytes = (unsigned)p.M * 16u;
@@ -163,7 +159,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
 #pragma unroll
                 for (int g = 0; g < C::PG; ++g)
                     if (g < npg) {
-                        if (C::CTAB_IN_RING && pl == 3 && g == C::PG - 1 && (cc & 1)) {   // the synchronisation words live in these four pixels
+                        if (C::TIGHT && pl == 3 && g == C::PG - 1 && (cc & 1)) {   // the synchronisation words live in these four pixels
                             if (lane < 60) bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
                         } else {
                             bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
@@ -186,16 +182,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
                 __builtin_amdgcn_s_sleep(1);
             }
         };
-        const __amdgpu_buffer_rsrc_t rct = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctab, 0, p.Cout * 16, 0x00020000);
-        if (!C::CTAB_IN_RING && dw == 0) bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16));   // oldest: landed before anything else
-        issue_band(0);
+        // first operands on their way before anything else happens in this workgroup (W(0) and the band first: step 0 needs them)
+        issue_w(0);
+        const int nb0 = issue_band(0);
 #pragma unroll
-        for (int s = 0; s < C::WS - 1; ++s) issue_w(s);   // launcher: nsteps >= 6 > WS - 1
-        wait_vmcnt<(C::WS - 2) * C::WPI>();   // band(0), W(0)
+        for (int s = 1; s < C::WS - 1; ++s) issue_w(s);   // launcher: nsteps >= 6 > WS - 1
+        const int nct = (!C::TIGHT && dw == 0) ? 1 : 0;
+        if (nct) bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16));
+        (void)nb0;
+        __builtin_amdgcn_s_barrier();   // the synchronisation words are initialised (MFMA wave 0); a bare barrier: no vmcnt(0) in front of it
+        wait_vm_upto<(C::WS - 2) * C::WPI + 1>((C::WS - 2) * C::WPI + nct);   // W(0), band(0)
         publish(1);
         int cc = 0, kh = 0;
-        // pieces (band, W) this wave issued in the last three iterations; the prologue's W(2 ..) count as iterations -1, -2, ...
-        int hb1 = 0, hw1 = C::WPI, hb2 = 0, hw2 = C::WS >= 5 ? C::WPI : 0, hb3 = 0, hw3 = C::WS >= 6 ? C::WPI : 0;
+        // pieces (band, W) this wave issued in the last three iterations; the prologue's W(2 ..) (+ the constants) count as iterations -1, -2, ...
+        int hb1 = 0, hw1 = C::WPI + nct, hb2 = 0, hw2 = C::WS >= 5 ? C::WPI : 0, hb3 = 0, hw3 = C::WS >= 6 ? C::WPI : 0;
         for (int i = 0; i < nsteps; ++i) {
             // (1) W(i + 1) - the last piece of iteration i + 2 - WS - has landed once at most the pieces of the WS - 3 iterations after it
             //     are in flight (LDS-DMA returns in order).  If step i + 1 opens a slice, its band was the FIRST thing iteration i - 2
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
             // (2) refill: ring stage (i - 1) % WS and band stage (cc + 1) & 1 are free once every MFMA wave is done with step i - 1
             int nb = 0, nw = 0;
             const int s2 = i + C::WS - 1;
-            const bool wantb = kh == 0 && cc + 1 < cchunks, wantw = s2 < nsteps, wantc = C::CTAB_IN_RING && s2 == nsteps && dw == 0;
+            const bool wantb = kh == 0 && cc + 1 < cchunks, wantw = s2 < nsteps, wantc = C::TIGHT && s2 == nsteps && dw == 0;
             if ((wantb || wantw || wantc) && !HAWQ_DBG_BIT(p.dbg, 1)) {
                 wait_done(i);
                 if (wantb) nb = issue_band(cc + 1);
@@ -224,61 +224,77 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         return;                // (the MFMA waves' epilogue barriers: ended waves are not counted by s_barrier)
     }
 
-    // ---------------------------------------------------------------------- MFMA waves: 64 px x 64 ch, k-half g of every slice
+    // ---------------------------------------------------------------------- MFMA waves: PT x 2 tiles, k-half g of every slice
+    if (t < 16) {
+        const bool used = t < 4 ? t < C::NPROD : (t < 12 ? t - 4 < C::NW : false);
+        *reinterpret_cast<int *>(smem + C::OFF_SYNC + t * 4) = t >= 12 ? 0 : (used ? 0 : 0x7fffffff);
+    }
     const int wave_m = wave % C::WM, g = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
-    int bp0[2], yy[2];
+    int bpx[C::PT];        // band pixel of this lane's output pixel
+    unsigned vm[C::PT];    // validity bit kh * 3 + kw: the tap stays inside the pixel's image
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int m = m0 + wave_m * 64 + q * 32 + l31;
+    for (int q = 0; q < C::PT; ++q) {
+        int m = m0 + wave_m * (32 * C::PT) + q * 32 + l31;
         m = m < p.M ? m : p.M - 1;
-        const int Gr = m / Wo, x = m - Gr * Wo;
-        bp0[q] = (Gr - G0 - 1) * Wb + x;   // band pixel of tap (kh = 0, kw = 0)
-        yy[q] = Gr % p.Ho;
+        const int Gr = m / Wo, x = m - Gr * Wo, y = Gr % p.Ho;
+        bpx[q] = m - mb0;
+        unsigned v = 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                if ((unsigned)(y + kh - 1) < (unsigned)p.Ho && (unsigned)(x + kw - 1) < (unsigned)Wo) v |= 1u << (kh * 3 + kw);
+        vm[q] = v;
     }
     unsigned wofs[2];   // A-fragment byte offsets inside a tap tile (swizzled rows), this group's k-half
 #pragma unroll
     for (int c = 0; c < 2; ++c) wofs[c] = lds_off(c * 32 + cperm(l31), 2 * g + h);
     const unsigned band_a = lds_addr(band) + (unsigned)((2 * g + h) * C::PLANE), wring_a = lds_addr(wring);
+    const unsigned zero_a = sync_a + 48;
 
-    v16i acc[2][2];
+    v16i acc[2][C::PT];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < C::PT; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
 
-    unsigned ap[2], wp[2];
+    unsigned ap[3][C::PT], wp[2];   // fragment addresses of the current step: [tap kw][pixel tile] (tap offset folded in), W bases
     auto bases = [&](int s, int cc, int kh) {
         const unsigned bst = band_a + (unsigned)((cc & 1) * C::BAND_BYTES), wst = wring_a + (unsigned)((s % C::WS) * C::WSTAGE);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bool rowok = (unsigned)(yy[q] + kh - 1) < (unsigned)p.Ho;   // else: another image's row / the padding -> zeros
-            ap[q] = bst + (unsigned)((rowok ? bp0[q] + kh * Wb : zp) * 16);
+        for (int q = 0; q < C::PT; ++q) {
+            const unsigned rb = bst + (unsigned)((bpx[q] + (kh - 1) * Wo - 1) * 16);   // tap kw = 0 of this filter row
+            const unsigned bits = vm[q] >> (kh * 3);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) ap[kw][q] = (bits >> kw) & 1u ? rb + kw * 16 : zero_a;
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) wp[c] = wst + wofs[c];
     };
     // three fragment buffers, one per tap of a step (fixed roles: no buffer parity across steps); the fragments of the next tap -
     // after tap 2: tap 0 of the next step - are requested before the MFMAs of the current one
-    v4i wf[3][2], af[3][2];
+    v4i wf[3][2], af[3][C::PT];
 #define V2_FETCH(KW)                                                                                  \
     if (!HAWQ_DBG_BIT(p.dbg, 4)) {                                                                    \
         _Pragma("unroll") for (int c = 0; c < 2; ++c) wf[KW][c] = lds_read16<(KW) * C::WTAP>(wp[c]);  \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) af[KW][q] = lds_read16<(KW) * 16>(ap[q]);       \
+        _Pragma("unroll") for (int q = 0; q < C::PT; ++q) af[KW][q] = lds_read16<0>(ap[KW][q]);       \
     }
 #define V2_MMA(KW)                                                                                    \
     {                                                                                                 \
         _Pragma("unroll") for (int c = 0; c < 2; ++c) pin(wf[KW][c]);                                  \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) pin(af[KW][q]);                                  \
+        _Pragma("unroll") for (int q = 0; q < C::PT; ++q) pin(af[KW][q]);                              \
         if (!HAWQ_DBG_BIT(p.dbg, 2)) {                                                                \
-            _Pragma("unroll") for (int c = 0; c < 2; ++c)                                             \
-                _Pragma("unroll") for (int q = 0; q < 2; ++q)                                         \
+            _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                         \
+                _Pragma("unroll") for (int c = 0; c < 2; ++c)                                         \
                     acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[KW][c], af[KW][q], acc[c][q], 0, 0, 0); \
         }                                                                                             \
     }
+    constexpr int NF = 2 + C::PT;   // fragment reads per tap
     const long long t_begin = prof ? (long long)__builtin_readcyclecounter() : 0;
+    __syncthreads();   // the synchronisation words are initialised
     const unsigned done_a = sync_a + 16u + (unsigned)(wave * 4);
     v4i pl;   // landed[] as requested at the top of a step
     auto ensure = [&](int n) {   // every producer's landed[] >= n; `pl` is covered by a fragment wait, the slow path spins
@@ -295,14 +311,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         V2_FETCH(0)
         for (int s = 0; s < nsteps; ++s) {
             asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(sync_a) : "memory");   // for the prefetch at the end of this step
-            V2_FETCH(1) wait_lgkm<4>(); V2_MMA(0)
-            V2_FETCH(2) wait_lgkm<4>(); V2_MMA(1)
+            V2_FETCH(1) wait_lgkm<NF>(); V2_MMA(0)
+            V2_FETCH(2) wait_lgkm<NF>(); V2_MMA(1)
             if (++kh == 3) kh = 0, ++cc;
             if (s + 1 < nsteps) {   // first fragments of the next step
                 ensure(s + 2);
                 bases(s + 1, cc, kh);
                 V2_FETCH(0)
-                wait_lgkm<4>();
+                wait_lgkm<NF>();
             } else {
                 wait_lgkm<0>();
             }
@@ -318,57 +334,69 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     while (lds_min4_now(sync_a) < nsteps + 2) __builtin_amdgcn_s_sleep(1);   // the producers are through (requant constants landed)
     __syncthreads();   // MFMA waves only (ended waves do not count): every wave is done with band and ring, which the exchange reuses
     // ---------------------------------------------------------------------- partial sums of the two k-halves meet in LDS
-    // wave (wave_m, g) keeps pixel tile q = g and hands its accumulators of pixel tile 1 - g to wave (wave_m, 1 - g)
-    v16i sum[2];
+    // wave (wave_m, g) keeps pixel tiles g * HQ .. g * HQ + HQ - 1 and hands the accumulators of the others to wave (wave_m, 1 - g)
+    v16i sum[2][C::HQ];
     auto exchange = [&](auto G) {
         constexpr int gg = decltype(G)::value;
         char *dst = smem + (wave_m + (1 - gg) * C::WM) * C::XCH + lane * 16;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int qq = 0; qq < C::HQ; ++qq)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const v4i v = {acc[c][1 - gg][4 * i], acc[c][1 - gg][4 * i + 1], acc[c][1 - gg][4 * i + 2], acc[c][1 - gg][4 * i + 3]};
-                *reinterpret_cast<v4i *>(dst + (c * 4 + i) * 1024) = v;
-            }
-        __syncthreads();   // MFMA waves only: the producers have ended
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v16i &a = acc[c][(1 - gg) * C::HQ + qq];
+                    const v4i v = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+                    *reinterpret_cast<v4i *>(dst + ((qq * 2 + c) * 4 + i) * 1024) = v;
+                }
+        __syncthreads();
         const char *src = smem + wave * C::XCH + lane * 16;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int qq = 0; qq < C::HQ; ++qq)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const v4i v = *reinterpret_cast<const v4i *>(src + (c * 4 + i) * 1024);
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sum[c][4 * i + j] = acc[c][gg][4 * i + j] + v[j];
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const v4i v = *reinterpret_cast<const v4i *>(src + ((qq * 2 + c) * 4 + i) * 1024);
+                    const v16i &a = acc[c][gg * C::HQ + qq];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum[c][qq][4 * i + j] = a[4 * i + j] + v[j];
+                }
     };
     if (g == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
     const long long t_xch = prof ? (long long)__builtin_readcyclecounter() : 0;
     // ---------------------------------------------------------------------- requantisation + stores (no staging tile)
-    const int m = m0 + wave_m * 64 + g * 32 + l31;
-    const bool mok = m < p.M;
     if constexpr (EPI == HAWQ_EPI_REQUANT) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int lch = c * 32 + h * 16;
-            int w[4];
+            int w[C::HQ][4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                int qv[4];
+                DyNt d[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const v4i e = *reinterpret_cast<const v4i *>(ctab_lds + (lch + 4 * gq + j) * 16);
-                    DyNt d;
-                    d.m = e.x, d.s = e.y & 31, d.k = e.y >> 8;
-                    d.add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
-                    qv[j] = med3i(dyadic_mode<MODE>(sum[c][4 * gq + j], d), p.q_lo, p.q_hi);
+                    d[j].m = e.x, d[j].s = e.y & 31, d[j].k = e.y >> 8;
+                    d[j].add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
                 }
-                w[gq] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+#pragma unroll
+                for (int qq = 0; qq < C::HQ; ++qq) {
+                    int qv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qv[j] = med3i(dyadic_mode<MODE>(sum[c][qq][4 * gq + j], d[j]), p.q_lo, p.q_hi);
+                    w[qq][gq] = pack4_fast(qv[0], qv[1], qv[2], qv[3]);
+                }
             }
-            const v4i ww = {w[0], w[1], w[2], w[3]};
-            if (mok && !HAWQ_DBG_BIT(p.dbg, 8)) {
-                char *dst = p.out_planar ? p.out + ((size_t)((c0 >> 4) + 2 * c + h) * p.M + m) * 16
-                                         : p.out + (size_t)m * p.Cout + c0 + lch;
-                *reinterpret_cast<v4i *>(dst) = ww;
+#pragma unroll
+            for (int qq = 0; qq < C::HQ; ++qq) {
+                const int m = m0 + wave_m * (32 * C::PT) + (g * C::HQ + qq) * 32 + l31;
+                const v4i ww = {w[qq][0], w[qq][1], w[qq][2], w[qq][3]};
+                if (m < p.M && !HAWQ_DBG_BIT(p.dbg, 8)) {
+                    char *dst = p.out_planar ? p.out + ((size_t)((c0 >> 4) + 2 * c + h) * p.M + m) * 16
+                                             : p.out + (size_t)m * p.Cout + c0 + lch;
+                    *reinterpret_cast<v4i *>(dst) = ww;
+                }
             }
         }
     }
@@ -379,15 +407,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     }
 }
 
-using V128 = V2Cfg<2, 2, 4, 256, 3>;    // 128 px x 64 ch: 4 MFMA + 2 producer waves, 80 KiB: two workgroups per CU
-using V256 = V2Cfg<4, 4, 4, 512, 3>;    // 256 px x 64 ch: 8 MFMA + 4 producer waves, 112 KiB
-using V256S = V2Cfg<4, 4, 5, 384, 3>;   // the same for maps whose band fits 384 band pixels (14 x 14, 7 x 7): 5-stage ring, 108 KiB
-constexpr int NUM_V2 = 3;
+// <PT, WM, NPROD, WS, BAND_PX, MINW>
+using V128 = V2Cfg<2, 2, 2, 4, 256, 3>;    // 128 px x 64 ch: 4 MFMA waves (64 x 64) + 2 producers, 80 KiB: two workgroups per CU
+using V128B = V2Cfg<4, 1, 2, 4, 256, 2>;   // 128 px x 64 ch: 2 MFMA waves (128 x 64) + 2 producers, 80 KiB
+using V256 = V2Cfg<4, 2, 4, 5, 384, 2>;    // 256 px x 64 ch: 4 MFMA waves (128 x 64) + 4 producers, 109 KiB
+using V256B = V2Cfg<2, 4, 4, 5, 384, 3>;   // 256 px x 64 ch: 8 MFMA waves (64 x 64) + 4 producers
+constexpr int NUM_V2 = 4;
 
 typedef void (*V2Fn)(const B2P);
-struct V2Info { V2Fn fn[2]; int bm, band_px, lds, nt; };
-#define V2_ENTRY(CFG) {{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2>}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT}
-const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V256), V2_ENTRY(V256S)};
+struct V2Info { V2Fn fn[2]; int bm, band_px, lds, nt, tight; };
+#define V2_ENTRY(CFG) {{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2>}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
+const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V128B), V2_ENTRY(V256), V2_ENTRY(V256B)};
 
 }  // namespace
 
@@ -413,12 +443,12 @@ extern "C" int hawq_pack_w3x3_band(const int8_t *src, int8_t *dst, int32_t Cout,
 bool band_v2_applies(const hawq_conv_args *a, int v) {
     if (v < 0 || v >= NUM_V2) return false;
     const V2Info &vi = kV2[v];
-    const int wo = a->W, band_rows = (vi.bm + wo - 1) / wo + 1 + 2;
     const long long M = (long long)a->N * a->H * a->W;
+    const int band_len = vi.bm + 2 * a->W + 2 + 7;   // pixels m0 - Wo - 1 .. m0 + BM + Wo, start rounded down to a line
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
            a->in_planar == 1 && a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 &&
            a->ctab && (a->in_pitch == 0 || a->in_pitch == a->Cin) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
-           band_rows * (wo + 2) + 8 <= vi.band_px && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
+           band_len <= vi.band_px - (vi.tight ? 4 : 0) && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
 }
 
 int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream) {
@@ -426,7 +456,7 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     B2P p;
     p.in = (const char *)a->in, p.wgt = (const char *)a->wgt_band, p.ctab = a->ctab, p.out = (char *)a->out_q;
     p.res_in = (const char *)a->res_in, p.res_out = (char *)a->res_out, p.flags = a->flags;
-    p.M = a->N * a->H * a->W, p.rows_total = a->N * a->H, p.Ho = a->H, p.Wo = a->W, p.Cin = a->Cin, p.Cout = a->Cout;
+    p.M = a->N * a->H * a->W, p.Ho = a->H, p.Wo = a->W, p.Cin = a->Cin, p.Cout = a->Cout;
     p.cchunks = a->Cin >> 6, p.nsteps = 3 * p.cchunks;
     p.out_planar = a->out_planar;
     p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
@@ -450,8 +480,8 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
         long long hb[6];
         (void)hipStreamSynchronize((hipStream_t)stream);
         (void)hipMemcpy(hb, p.dbgbuf, sizeof(hb), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[band-v2 bm=%d M=%d Cin=%d Cout=%d grid=%d lds=%d] steps %lld: prologue %lld | K loop %lld | epilogue %lld cycles (wave 0 of workgroup 8); wait at barrier 0 %lld, exchange %lld\n",
-                vi.bm, p.M, p.Cin, p.Cout, grid, vi.lds, hb[3], hb[0], hb[1], hb[2], hb[4], hb[5]);
+        fprintf(stderr, "[band-v2 %d bm=%d M=%d Cin=%d Cout=%d grid=%d lds=%d] steps %lld: prologue %lld | K loop %lld | epilogue %lld cycles (wave 0 of workgroup 8); first operands %lld, exchange %lld\n",
+                v, vi.bm, p.M, p.Cin, p.Cout, grid, vi.lds, hb[3], hb[0], hb[1], hb[2], hb[4], hb[5]);
     }
     return 0;
 }
