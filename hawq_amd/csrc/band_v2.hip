@@ -61,13 +61,15 @@ struct V2Cfg {
     static constexpr int PLANE = BAND_PX * 16, BAND_BYTES = 4 * PLANE;
     static constexpr int WTAP = 4096, WSTAGE = 3 * WTAP;
     static constexpr int OFF_W = 2 * BAND_BYTES, RING_END = OFF_W + WS * WSTAGE;
-    // A tile that must fit 80 KiB twice per CU has no byte to spare: its requant constants land in the first ring stage the K loop
-    // releases for good, and its 64 bytes of synchronisation words are the last four pixels of plane 3 of band stage 1, which no tap
-    // reads (launcher: band length <= BAND_PX - 4) and whose four lanes the band fill masks off (an LDS-DMA writes nothing for lanes
-    // EXEC has switched off: tools/ubench/dma_exec.hip).  The larger tiles have the CU to themselves and own 1 KiB + 64 B for them.
+    // The last four pixels of plane 3 of either band stage are never read as pixels (launcher: band length <= BAND_PX - 4) and never
+    // written by the band fill, which masks their four lanes off (an LDS-DMA writes nothing for lanes EXEC has switched off:
+    // tools/ubench/dma_exec.hip).  Byte BAND_BYTES - 16 of either stage is the zero word the out-of-image taps read (the SAME offset in
+    // both stages: a tap address is stage base + a per-lane constant), bytes BAND_BYTES - 64 .. - 17 of stage 1 are the
+    // synchronisation words.  A tile that must fit 80 KiB twice per CU has no other byte to spare: its requant constants land in the
+    // first ring stage the K loop releases for good; the larger tiles have the CU to themselves and own a KiB for them.
     static constexpr bool TIGHT = RING_END == 80 * 1024;
-    static constexpr int OFF_CTAB = RING_END, OFF_SYNC = TIGHT ? 2 * BAND_BYTES - 64 : RING_END + 1024;
-    static constexpr int LDS_BYTES = RING_END + (TIGHT ? 0 : 1024 + 64);
+    static constexpr int OFF_CTAB = RING_END, OFF_SYNC = 2 * BAND_BYTES - 64, ZERO_OFF = BAND_BYTES - 16;
+    static constexpr int LDS_BYTES = RING_END + (TIGHT ? 0 : 1024);
     static constexpr int PG = BAND_PX / 64;             // 64-pixel groups per plane
     static constexpr int PPP = 4 / NPROD;               // planes per producer wave
     static constexpr int BPI = PG * PPP, WPI = 12 / NPROD;
@@ -75,9 +77,8 @@ struct V2Cfg {
     static constexpr int XCH = HQ * 2 * 16 * 256;       // exchange area per MFMA wave: HQ x 2 tiles x 16 registers x 64 lanes x 4 B
     static_assert(PT == 2 || PT == 4, "pixel tiles per MFMA wave");
     static_assert(NPROD == 2 || NPROD == 4, "producer waves");
-    static_assert(BAND_PX % 64 == 0 && WS >= 4 && WS <= 6, "ring");
+    static_assert(BAND_PX % 64 == 0 && WS >= 4 && WS <= 5, "ring");
     static_assert(NW * XCH <= (TIGHT ? 2 * BAND_BYTES : RING_END), "the partial-sum exchange reuses the band area (and the ring)");
-    static_assert(3 * (BPI + WPI) <= 60, "vmcnt is a 6-bit counter");
 };
 
 __device__ __forceinline__ void bdma(__amdgpu_buffer_rsrc_t r, char *lds, unsigned voff, unsigned soff) {
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     const int nsteps = p.nsteps, cchunks = p.cchunks;
     char *const band = smem, *const wring = smem + C::OFF_W;
     char *const ctab_lds = C::TIGHT ? wring + (nsteps % C::WS) * C::WSTAGE : smem + C::OFF_CTAB;
-    const unsigned sync_a = lds_addr(smem + C::OFF_SYNC);   // landed[4] at +0, done[8] at +16, 16 zero bytes at +48
+    const unsigned sync_a = lds_addr(smem + C::OFF_SYNC);   // landed[4] at +0, done[8] at +16 (the zero word of band stage 1 at +48)
 
     if (wave >= C::NW) {
         // ------------------------------------------------------------------ producer waves: every LDS-DMA of the kernel
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
 #pragma unroll
                 for (int g = 0; g < C::PG; ++g)
                     if (g < npg) {
-                        if (C::TIGHT && pl == 3 && g == C::PG - 1 && (cc & 1)) {   // the synchronisation words live in these four pixels
+                        if (pl == 3 && g == C::PG - 1) {   // zero word / synchronisation words live in these four pixels
                             if (lane < 60) bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
                         } else {
                             bdma(rin, dst + pl * C::PLANE + g * 1024, bvo[g], so);
@@ -192,31 +193,29 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         (void)nb0;
         __builtin_amdgcn_s_barrier();   // the synchronisation words are initialised (MFMA wave 0); a bare barrier: no vmcnt(0) in front of it
         wait_vm_upto<(C::WS - 2) * C::WPI + 1>((C::WS - 2) * C::WPI + nct);   // W(0), band(0)
-        publish(1);
+        publish(1);   // (the loop's first publish is WS - 2 >= 2)
         int cc = 0, kh = 0;
-        // pieces (band, W) this wave issued in the last three iterations; the prologue's W(2 ..) (+ the constants) count as iterations -1, -2, ...
-        int hb1 = 0, hw1 = C::WPI + nct, hb2 = 0, hw2 = C::WS >= 5 ? C::WPI : 0, hb3 = 0, hw3 = C::WS >= 6 ? C::WPI : 0;
+        int hw1 = C::WPI + nct;   // W (/ constants) pieces of the previous iteration - of the prologue's last stage at first
         for (int i = 0; i < nsteps; ++i) {
-            // (1) W(i + 1) - the last piece of iteration i + 2 - WS - has landed once at most the pieces of the WS - 3 iterations after it
-            //     are in flight (LDS-DMA returns in order).  If step i + 1 opens a slice, its band was the FIRST thing iteration i - 2
-            //     issued: then only the pieces behind it may stay
-            int allow = hb1 + hw1;
-            if (C::WS >= 5) allow += hb2 + hw2;
-            if (C::WS >= 6) allow += hb3 + hw3;
-            if (kh == 2) allow = min(allow, hw2 + hb1 + hw1);
-            wait_vm_upto<3 * (C::BPI + C::WPI)>(allow);
-            publish(i + 2);
+            // (1) Everything but the W pieces of the previous iteration has landed (LDS-DMA returns in order; an iteration issues its band
+            //     pieces first): W(0 .. i + WS - 3), and every band issued so far - the band of slice c is issued in iteration 3c - 3, so the
+            //     bands of steps <= i + 2 are there, which covers step i + WS - 3 as long as WS <= 5.  Publishing as far ahead as the ring
+            //     allows matters: landed[] is what lets an MFMA wave run ahead of the slowest one, and with a count that trailed the ring by
+            //     two stages the K loop ran at the pace of the flag round trips (1030 cycles per step with no arithmetic at all).
+            wait_vm_upto<C::WPI + 1>(hw1);
+            publish(i + C::WS - 2);
             // (2) refill: ring stage (i - 1) % WS and band stage (cc + 1) & 1 are free once every MFMA wave is done with step i - 1
             int nb = 0, nw = 0;
             const int s2 = i + C::WS - 1;
             const bool wantb = kh == 0 && cc + 1 < cchunks, wantw = s2 < nsteps, wantc = C::TIGHT && s2 == nsteps && dw == 0;
             if ((wantb || wantw || wantc) && !HAWQ_DBG_BIT(p.dbg, 1)) {
                 wait_done(i);
-                if (wantb) nb = issue_band(cc + 1);
-                if (wantw) issue_w(s2), nw = C::WPI;
+                if (wantb && !HAWQ_DBG_BIT(p.dbg, 64)) nb = issue_band(cc + 1);
+                if (wantw && !HAWQ_DBG_BIT(p.dbg, 32)) issue_w(s2), nw = C::WPI;
                 if (wantc) bdma(rct, ctab_lds, (unsigned)(lane * 16), (unsigned)(c0 * 16)), nw = 1;
             }
-            hb3 = hb2, hw3 = hw2, hb2 = hb1, hw2 = hw1, hb1 = nb, hw1 = nw;
+            hw1 = nw;
+            (void)nb;
             if (++kh == 3) kh = 0, ++cc;
         }
         wait_vmcnt<0>();
@@ -227,31 +226,31 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     // ---------------------------------------------------------------------- MFMA waves: PT x 2 tiles, k-half g of every slice
     if (t < 16) {
         const bool used = t < 4 ? t < C::NPROD : (t < 12 ? t - 4 < C::NW : false);
-        *reinterpret_cast<int *>(smem + C::OFF_SYNC + t * 4) = t >= 12 ? 0 : (used ? 0 : 0x7fffffff);
+        *reinterpret_cast<int *>(smem + C::OFF_SYNC + t * 4) = t >= 12 ? 0 : (used ? 0 : 0x7fffffff);   // stage 1: counters + zero word
+        *reinterpret_cast<int *>(smem + C::BAND_BYTES - 64 + t * 4) = 0;                                  // stage 0: zero word
     }
     const int wave_m = wave % C::WM, g = wave / C::WM;
     const int l31 = lane & 31, h = lane >> 5;
-    int bpx[C::PT];        // band pixel of this lane's output pixel
-    unsigned vm[C::PT];    // validity bit kh * 3 + kw: the tap stays inside the pixel's image
+    // byte offset of tap (kh, kw) of this lane's pixel from the base of a band stage: its k-half's plane + the dense band pixel, or the
+    // stage's zero word when the tap leaves the pixel's image (the only per-step address arithmetic left is one add per fragment)
+    unsigned off[C::PT][9];
 #pragma unroll
     for (int q = 0; q < C::PT; ++q) {
         int m = m0 + wave_m * (32 * C::PT) + q * 32 + l31;
         m = m < p.M ? m : p.M - 1;
         const int Gr = m / Wo, x = m - Gr * Wo, y = Gr % p.Ho;
-        bpx[q] = m - mb0;
-        unsigned v = 0;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-                if ((unsigned)(y + kh - 1) < (unsigned)p.Ho && (unsigned)(x + kw - 1) < (unsigned)Wo) v |= 1u << (kh * 3 + kw);
-        vm[q] = v;
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool v = (unsigned)(y + kh - 1) < (unsigned)p.Ho && (unsigned)(x + kw - 1) < (unsigned)Wo;
+                off[q][kh * 3 + kw] = v ? (unsigned)((2 * g + h) * C::PLANE + (m - mb0 + (kh - 1) * Wo + kw - 1) * 16) : (unsigned)C::ZERO_OFF;
+            }
     }
     unsigned wofs[2];   // A-fragment byte offsets inside a tap tile (swizzled rows), this group's k-half
 #pragma unroll
     for (int c = 0; c < 2; ++c) wofs[c] = lds_off(c * 32 + cperm(l31), 2 * g + h);
-    const unsigned band_a = lds_addr(band) + (unsigned)((2 * g + h) * C::PLANE), wring_a = lds_addr(wring);
-    const unsigned zero_a = sync_a + 48;
+    const unsigned band_a = lds_addr(band), wring_a = lds_addr(wring);
 
     v16i acc[2][C::PT];
 #pragma unroll
@@ -261,26 +260,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][q][r] = 0;
 
-    unsigned ap[3][C::PT], wp[2];   // fragment addresses of the current step: [tap kw][pixel tile] (tap offset folded in), W bases
-    auto bases = [&](int s, int cc, int kh) {
-        const unsigned bst = band_a + (unsigned)((cc & 1) * C::BAND_BYTES), wst = wring_a + (unsigned)((s % C::WS) * C::WSTAGE);
-#pragma unroll
-        for (int q = 0; q < C::PT; ++q) {
-            const unsigned rb = bst + (unsigned)((bpx[q] + (kh - 1) * Wo - 1) * 16);   // tap kw = 0 of this filter row
-            const unsigned bits = vm[q] >> (kh * 3);
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) ap[kw][q] = (bits >> kw) & 1u ? rb + kw * 16 : zero_a;
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wp[c] = wst + wofs[c];
-    };
     // three fragment buffers, one per tap of a step (fixed roles: no buffer parity across steps); the fragments of the next tap -
     // after tap 2: tap 0 of the next step - are requested before the MFMAs of the current one
     v4i wf[3][2], af[3][C::PT];
-#define V2_FETCH(KW)                                                                                  \
+#define V2_FETCH(KH, KW, BST, WST)                                                                    \
     if (!HAWQ_DBG_BIT(p.dbg, 4)) {                                                                    \
-        _Pragma("unroll") for (int c = 0; c < 2; ++c) wf[KW][c] = lds_read16<(KW) * C::WTAP>(wp[c]);  \
-        _Pragma("unroll") for (int q = 0; q < C::PT; ++q) af[KW][q] = lds_read16<0>(ap[KW][q]);       \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) wf[KW][c] = lds_read16<(KW) * C::WTAP>((WST) + wofs[c]); \
+        _Pragma("unroll") for (int q = 0; q < C::PT; ++q) af[KW][q] = lds_read16<0>((BST) + off[q][(KH) * 3 + (KW)]); \
     }
 #define V2_MMA(KW)                                                                                    \
     {                                                                                                 \
@@ -306,25 +292,37 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     const long long t_b0 = prof ? (long long)__builtin_readcyclecounter() : 0;
     __builtin_amdgcn_s_setprio(2);
     {
-        int cc = 0, kh = 0;
-        bases(0, 0, 0);
-        V2_FETCH(0)
-        for (int s = 0; s < nsteps; ++s) {
-            asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(sync_a) : "memory");   // for the prefetch at the end of this step
-            V2_FETCH(1) wait_lgkm<NF>(); V2_MMA(0)
-            V2_FETCH(2) wait_lgkm<NF>(); V2_MMA(1)
-            if (++kh == 3) kh = 0, ++cc;
-            if (s + 1 < nsteps) {   // first fragments of the next step
-                ensure(s + 2);
-                bases(s + 1, cc, kh);
-                V2_FETCH(0)
-                wait_lgkm<NF>();
-            } else {
-                wait_lgkm<0>();
-            }
-            lds_store_b32(done_a, s + 1);   // every fragment read of step s has returned: its ring stage (and, after kh == 2, its band) is free
-            V2_MMA(2)
+        int s = 0, ws = 0;   // step, its ring stage
+        unsigned bst = band_a, wst = wring_a;
+        V2_FETCH(0, 0, bst, wst)
+        // one step: taps kw = 0 / 1 / 2 of filter row KH; NKH / bnext: filter row and band stage of the next step
+#define V2_STEP(KH, NKH, BNEXT, LAST)                                                                       \
+        {                                                                                                   \
+            asm volatile("ds_read_b128 %0, %1" : "=v"(pl) : "v"(sync_a) : "memory");   /* for the prefetch below */ \
+            V2_FETCH(KH, 1, bst, wst) wait_lgkm<NF>(); V2_MMA(0)                                            \
+            V2_FETCH(KH, 2, bst, wst) wait_lgkm<NF>(); V2_MMA(1)                                            \
+            if (++ws == C::WS) ws = 0;                                                                      \
+            const unsigned wnext = wring_a + (unsigned)(ws * C::WSTAGE);                                    \
+            if (!(LAST)) {   /* first fragments of the next step */                                         \
+                ensure(s + 2);                                                                              \
+                V2_FETCH(NKH, 0, BNEXT, wnext)                                                              \
+                wait_lgkm<NF>();                                                                            \
+            } else {                                                                                        \
+                wait_lgkm<0>();                                                                             \
+            }                                                                                               \
+            lds_store_b32(done_a, s + 1);   /* every fragment read of step s has returned: ring stage (and band) free */ \
+            V2_MMA(2)                                                                                       \
+            wst = wnext, ++s;                                                                               \
         }
+        for (int cc = 0; cc < cchunks; ++cc) {
+            const unsigned bother = band_a + (unsigned)(((cc + 1) & 1) * C::BAND_BYTES);
+            const bool last = cc + 1 == cchunks;
+            V2_STEP(0, 1, bst, false)
+            V2_STEP(1, 2, bst, false)
+            V2_STEP(2, 0, bother, last)
+            bst = bother;
+        }
+#undef V2_STEP
     }
 #undef V2_FETCH
 #undef V2_MMA
@@ -448,7 +446,7 @@ bool band_v2_applies(const hawq_conv_args *a, int v) {
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
            a->in_planar == 1 && a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 &&
            a->ctab && (a->in_pitch == 0 || a->in_pitch == a->Cin) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
-           band_len <= vi.band_px - (vi.tight ? 4 : 0) && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
+           band_len <= vi.band_px - 4 && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
 }
 
 int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream) {

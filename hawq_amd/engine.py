@@ -108,7 +108,12 @@ class _Conv:
         b = mod.bias_integer.detach().cpu().numpy().astype(np.float64)
         self.b_host = np.clip(np.rint(b), -2 ** 31, 2 ** 31 - 1).astype(np.int64)
         if self.cin % 64 == 0 and self.cout % 64 == 0:
-            self.w = torch.from_numpy(packing.pack_conv_weight(w_int, self.w_bits)).to(dev)
+            wp = packing.pack_conv_weight(w_int, self.w_bits)
+            self.w = torch.from_numpy(wp).to(dev)
+            # the round-5 3x3 kernels stream the same integers in tile order (include/hawq_mi355.h: hawq_conv_args.wgt_band)
+            self.w_band = None
+            if (self.kh, self.kw, self.stride, self.pad) == (3, 3, 1, 1) and self.w_bits == 8 and self.cin >= 128 and not os.environ.get("HAWQ_NO_BAND2"):
+                self.w_band = torch.from_numpy(packing.pack_w3x3_band(wp, self.cout, self.cin)).to(dev)
         self.bias = _i32(self.b_host, dev)
         # exact per-channel bound on |accumulator| -> bit length, for the requant pre-shift check
         amax = max(abs(int(in_range[0])), abs(int(in_range[1]))) if in_range is not None else (128 if in_bits == 8 else 15)
@@ -645,6 +650,8 @@ class IntegerEngine:
                 ho, wo = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
                 a = _lib.ConvArgs()
                 a.in_, a.wgt, a.bias = x_in.data_ptr(), c.w.data_ptr(), c.bias.data_ptr()
+                if getattr(c, "w_band", None) is not None and x_bits == 8:
+                    a.wgt_band = c.w_band.data_ptr()
                 a.N, a.H, a.W, a.Cin, a.Cout = N, hin, win, c.cin, c.cout
                 a.KH, a.KW, a.stride, a.pad = c.kh, c.kw, c.stride, c.pad
                 a.in_bits, a.w_bits = x_bits, c.w_bits
