@@ -329,6 +329,21 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     __builtin_amdgcn_s_setprio(0);
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
 
+    // RESIDUAL: this lane's old residual values (its HQ pixels x 2 x 16 channels, 32 contiguous bytes each) are requested now and
+    // arrive under the exchange
+    v4i rin[C::HQ][2][2];
+    if constexpr (EPI == HAWQ_EPI_RESIDUAL) {
+#pragma unroll
+        for (int qq = 0; qq < C::HQ; ++qq) {
+            int m = m0 + wave_m * (32 * C::PT) + (g * C::HQ + qq) * 32 + l31;
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const v4i *rp = reinterpret_cast<const v4i *>(p.res_in + ((size_t)m * p.Cout + c0 + c * 32 + h * 16) * 2);
+                rin[qq][c][0] = rp[0], rin[qq][c][1] = rp[1];
+            }
+        }
+    }
     while (lds_min4_now(sync_a) < nsteps + 2) __builtin_amdgcn_s_sleep(1);   // the producers are through (requant constants landed)
     __syncthreads();   // MFMA waves only (ended waves do not count): every wave is done with band and ring, which the exchange reuses
     // ---------------------------------------------------------------------- partial sums of the two k-halves meet in LDS
@@ -398,6 +413,65 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
             }
         }
     }
+    if constexpr (EPI == HAWQ_EPI_RESIDUAL) {
+        // second conv of a basic block (q_resnet.py:300-316): o = ReLU(requant(acc + bias) + requant(identity)), un-clamped
+        // (quant_utils.py:415-456), stored as uint16 with the sticky overflow flag; q = the next block's QuantAct of o
+        DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);
+        asm volatile("" : "+v"(dids.add), "+v"(dq.add));
+        const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);
+        unsigned oor = 0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int lch = c * 32 + h * 16;
+            int w[C::HQ][4], rp[C::HQ][8];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                DyNt d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4i e = *reinterpret_cast<const v4i *>(ctab_lds + (lch + 4 * gq + j) * 16);
+                    d[j].m = e.x, d[j].s = e.y & 31, d[j].k = e.y >> 8;
+                    d[j].add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
+                }
+#pragma unroll
+                for (int qq = 0; qq < C::HQ; ++qq) {
+                    const unsigned w0 = (unsigned)rin[qq][c][gq >> 1][(gq & 1) * 2], w1 = (unsigned)rin[qq][c][gq >> 1][(gq & 1) * 2 + 1];
+                    const int idin[4] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+                    int o[4], qv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int a = dyadic_mode<MODE>(sum[c][qq][4 * gq + j], d[j]);
+                        const int b = dyadic_mode<MODE == 2 ? 2 : 0>(idin[j], dids);
+                        o[j] = max(a + b, 0);
+                        qv[j] = dyadic_mode<MODE>(o[j], dq);   // o >= 0, m >= 0: q >= 0 >= q_lo; clamped from above in the pack
+                    }
+                    const int mrow = m0 + wave_m * (32 * C::PT) + (g * C::HQ + qq) * 32 + l31;
+                    if (mrow < p.M) oor |= (unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3]);
+                    rp[qq][2 * gq] = pack2_u16_sat(o[0], o[1]);
+                    rp[qq][2 * gq + 1] = pack2_u16_sat(o[2], o[3]);
+                    w[qq][gq] = pack4_min(qv[0], qv[1], qv[2], qv[3], qhi2);
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < C::HQ; ++qq) {
+                const int m = m0 + wave_m * (32 * C::PT) + (g * C::HQ + qq) * 32 + l31;
+                if (m < p.M && !HAWQ_DBG_BIT(p.dbg, 8)) {
+                    if (p.res_out) {
+                        v4i *dst = reinterpret_cast<v4i *>(p.res_out + ((size_t)m * p.Cout + c0 + lch) * 2);
+                        const v4i ra = {rp[qq][0], rp[qq][1], rp[qq][2], rp[qq][3]}, rb = {rp[qq][4], rp[qq][5], rp[qq][6], rp[qq][7]};
+                        dst[0] = ra, dst[1] = rb;
+                    }
+                    if (p.out) {
+                        const v4i ww = {w[qq][0], w[qq][1], w[qq][2], w[qq][3]};
+                        char *dst = p.out_planar ? p.out + ((size_t)((c0 >> 4) + 2 * c + h) * p.M + m) * 16
+                                                 : p.out + (size_t)m * p.Cout + c0 + lch;
+                        *reinterpret_cast<v4i *>(dst) = ww;
+                    }
+                }
+            }
+        }
+        if ((oor >> 16) != 0 && p.res_out && !HAWQ_DBG_BIT(p.dbg, ~0)) atomicOr(p.flags, 1);
+    }
     if (prof && blockIdx.x == 8 && t == 0) {
         p.dbgbuf[0] = t_begin - t_entry, p.dbgbuf[1] = t_loop_end - t_begin;
         p.dbgbuf[2] = (long long)__builtin_readcyclecounter() - t_loop_end, p.dbgbuf[3] = nsteps;
@@ -405,17 +479,18 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     }
 }
 
-// <PT, WM, NPROD, WS, BAND_PX, MINW>
-using V128 = V2Cfg<2, 2, 2, 4, 256, 3>;    // 128 px x 64 ch: 4 MFMA waves (64 x 64) + 2 producers, 80 KiB: two workgroups per CU
-using V128B = V2Cfg<4, 1, 2, 4, 256, 2>;   // 128 px x 64 ch: 2 MFMA waves (128 x 64) + 2 producers, 80 KiB
-using V256 = V2Cfg<4, 2, 4, 5, 384, 2>;    // 256 px x 64 ch: 4 MFMA waves (128 x 64) + 4 producers, 109 KiB
-using V256B = V2Cfg<2, 4, 4, 5, 384, 3>;   // 256 px x 64 ch: 8 MFMA waves (64 x 64) + 4 producers
-constexpr int NUM_V2 = 4;
+// <PT, WM, NPROD, WS, BAND_PX, MINW>.  (PT = 4 - 128 px x 64 ch per MFMA wave, 0.75 fragment reads per MFMA - compiles and is exact, but
+// 246 registers leave ONE MFMA wave per SIMD, whose own address / wait / flag instructions then sit between its MFMAs: 13.6 against
+// 12.4 us on the 14 x 14 layer, profiles/r05_band_v2.md.  Not instantiated.)
+using V128 = V2Cfg<2, 2, 2, 4, 256, 3>;    // 128 px x 64 ch: 4 MFMA waves (64 x 64 each, 2 k-halves) + 2 producers, 80 KiB: two workgroups per CU
+using V256 = V2Cfg<2, 4, 4, 5, 384, 3>;    // 256 px x 64 ch: 8 MFMA waves + 4 producers, 5-stage ring, 109 KiB
+constexpr int NUM_V2 = 2;
 
 typedef void (*V2Fn)(const B2P);
-struct V2Info { V2Fn fn[2]; int bm, band_px, lds, nt, tight; };
-#define V2_ENTRY(CFG) {{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2>}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
-const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V128B), V2_ENTRY(V256), V2_ENTRY(V256B)};
+struct V2Info { V2Fn fn[2][2]; int bm, band_px, lds, nt, tight; };   // fn[residual][exact-tie]
+#define V2_ENTRY(CFG) {{{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2>}, \
+                        {conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 2>}}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
+const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V256)};
 
 }  // namespace
 
@@ -443,8 +518,11 @@ bool band_v2_applies(const hawq_conv_args *a, int v) {
     const V2Info &vi = kV2[v];
     const long long M = (long long)a->N * a->H * a->W;
     const int band_len = vi.bm + 2 * a->W + 2 + 7;   // pixels m0 - Wo - 1 .. m0 + BM + Wo, start rounded down to a line
+    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8) ||
+                        (a->epilogue == HAWQ_EPI_RESIDUAL && a->res_in && a->res_in_bits == 16 && (!a->res_out || (a->res_out_bits == 16 && a->flags)) &&
+                         !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || a->out_bits == 8));
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
-           a->in_planar == 1 && a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 &&
+           a->in_planar == 1 && epi_ok && a->in_bits == 8 && a->w_bits == 8 &&
            a->ctab && (a->in_pitch == 0 || a->in_pitch == a->Cin) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
            band_len <= vi.band_px - 4 && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
 }
@@ -459,6 +537,7 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     p.out_planar = a->out_planar;
     p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
     p.mq = a->mq, p.eq = a->eq, p.m_id = a->m_id_scalar, p.e_id = a->e_id_scalar;
+    if (a->epilogue == HAWQ_EPI_RESIDUAL && !a->out_q) p.mq = 0, p.eq = 33;   // no next QuantAct: a harmless table
     p.in_bytes = (unsigned)((long long)p.M * a->Cin), p.wgt_bytes = (unsigned)((long long)a->Cout * a->Cin * 9);
     p.dbg = dbg;
     static long long *dbg_dev = nullptr;
@@ -467,12 +546,12 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     static const bool attrs = [] {
         bool good = true;
         for (const V2Info &i : kV2)
-            for (int k = 0; k < 2; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+            for (int k = 0; k < 4; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k >> 1][k & 1], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
         return good;
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv2d: hipFuncSetAttribute failed for the round-5 3x3 kernels");
     const int grid = ((p.M + vi.bm - 1) / vi.bm) * (p.Cout >> 6);
-    hipLaunchKernelGGL(vi.fn[exact_tie ? 1 : 0], dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(vi.fn[a->epilogue == HAWQ_EPI_RESIDUAL ? 1 : 0][exact_tie ? 1 : 0], dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {   // experiment hook (synchronises!)
         long long hb[6];

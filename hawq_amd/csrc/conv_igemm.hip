@@ -1453,7 +1453,8 @@ bool band_v2_applies(const hawq_conv_args *a, int v);
 int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream);
 
 extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count(); }  // the 3x3 kernels are the last ids
-extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES + 2; }  // + the weight-stationary kernel of band_persist.hip with 1 / 2 workgroups per CU
+// + the weight-stationary kernel of band_persist.hip with 1 / 2 workgroups per CU + the round-5 kernels of band_v2.hip
+extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES + 2 + band_v2_count(); }
 
 extern "C" int hawq_conv2d_num_band2_tiles(void) { return band_v2_count(); }
 extern "C" int hawq_conv2d_band2_tile(const hawq_conv_args *a) {

@@ -150,14 +150,15 @@ typedef struct hawq_conv_args {
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
 int hawq_conv2d_num_tiles(void);
 /* The LAST hawq_conv2d_num_band_tiles() tile ids are the 3x3/stride-1/pad-1 "band" kernels (fast-contract
- * layers only; hawq_conv2d refuses them for any other layer); the last two are the weight-stationary persistent
- * kernel for Cin == Cout == 64 (int8 in and out, REQUANT, NHWC output) with one / two workgroups per CU.  All other ids take any layer. */
+ * layers only; hawq_conv2d refuses them for any other layer): the band kernels of rounds 1-3, then the weight-stationary persistent
+ * kernel for Cin == Cout == 64 (int8 in and out, REQUANT, NHWC output) with one / two workgroups per CU, then (ABI 5) the
+ * hawq_conv2d_num_band2_tiles() kernels of round 5.  All other ids take any layer. */
 int hawq_conv2d_num_band_tiles(void);
 /* 1-based id of the preferred band tile that takes this layer as described (geometry, widths, epilogue,
  * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */
 int hawq_conv2d_band_tile(const hawq_conv_args *args);
-/* ABI 5: the hawq_conv2d_num_band2_tiles() tile ids AFTER the ones above are the round-5 3x3 kernels (need args->wgt_band and
- * in_planar == 1).  hawq_conv2d_band2_tile: 1-based id of the first of them that takes the layer as described, else 0.
+/* ABI 5: the LAST hawq_conv2d_num_band2_tiles() of those ids are the round-5 3x3 kernels (band_v2.hip; need args->wgt_band and
+ * in_planar == 1; int8 operands, Cin >= 128; REQUANT, or single-branch RESIDUAL on uint16 residuals; int8 NHWC or planar output).  hawq_conv2d_band2_tile: 1-based id of the first of them that takes the layer as described, else 0.
  * hawq_pack_w3x3_band: [Cout][3][3][Cin] int8 (the layout of `wgt`) -> the stream described at hawq_conv_args.wgt_band, on the host
  * (dst and src are host pointers of Cout * 9 * Cin bytes; Cin and Cout multiples of 64). */
 int hawq_conv2d_num_band2_tiles(void);

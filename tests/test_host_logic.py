@@ -527,3 +527,36 @@ def test_relu6_restated_as_relu_plus_clamp_is_exact_where_the_engine_accepts_it(
             assert not np.array_equal(ref, plan)
             no += 1
     assert yes > 20 and no > 20
+
+
+def test_pack_w3x3_band_matches_the_c_twin_and_a_loop_restatement():
+    """ABI 5: the weight stream of the round-5 3x3 kernels (include/hawq_mi355.h: hawq_conv_args.wgt_band).  The numpy packer the
+    engine uses, the C twin a non-Python host would call (hawq_pack_w3x3_band: host pointers, no GPU) and a loop restatement of the
+    documented layout agree byte for byte."""
+    import ctypes
+    from hawq_amd import _lib
+    from hawq_amd.packing import pack_w3x3_band
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for cout, cin in ((64, 128), (128, 192), (192, 64)):
+        w = rng.integers(-128, 128, (cout, 9, cin)).astype(np.int8)
+        got = pack_w3x3_band(w.view(np.uint8).reshape(-1), cout, cin)
+        ref = np.zeros(cout * 9 * cin, np.uint8)
+        cch = cin // 64
+        wu = w.view(np.uint8)
+        for ct in range(cout // 64):
+            for cc in range(cch):
+                for tap in range(9):
+                    base = ((ct * cch + cc) * 9 + tap) * 4096
+                    for r in range(64):
+                        row = wu[ct * 64 + r, tap, cc * 64:cc * 64 + 64]
+                        for sl in range(4):
+                            o = base + r * 64 + ((sl ^ ((r >> 2) & 3)) << 4)
+                            ref[o:o + 16] = row[sl * 16:sl * 16 + 16]
+        assert np.array_equal(got, ref)
+        dst = np.zeros_like(ref)
+        src = np.ascontiguousarray(wu.reshape(-1))
+        assert lib.hawq_pack_w3x3_band(src.ctypes.data_as(ctypes.c_void_p), dst.ctypes.data_as(ctypes.c_void_p), cout, cin) == 0
+        assert np.array_equal(dst, ref)
+    bad = np.zeros(16, np.uint8)
+    assert lib.hawq_pack_w3x3_band(bad.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), 32, 64) != 0
