@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
         ("in_planar", i32), ("out_planar", i32),
         ("res_no_relu", i32), ("res_clamp16", i32),
         ("in_pitch", i32), ("out_pitch", i32),
-        ("wgt_band", vp),
+        ("wgt_band", vp), ("wgt_k128", vp), ("wgt2_k128", vp),
     ]
 
 
@@ -63,6 +63,9 @@ SIGNATURES = {
     "hawq_conv2d_num_band2_tiles": [],
     "hawq_conv2d_band2_tile": [C.POINTER(ConvArgs)],
     "hawq_pack_w3x3_band": [vp, vp, i32, i32],
+    "hawq_conv2d_num_gemm2_tiles": [],
+    "hawq_conv2d_gemm2_first": [],
+    "hawq_pack_w1x1_k128": [vp, vp, i32, i32],
     "hawq_conv_expand_reduce": [C.POINTER(ExpandReduceArgs), vp],
     "hawq_conv_expand_reduce_variants": [C.POINTER(ExpandReduceArgs)],
     "hawq_linear_bottleneck": [C.POINTER(BottleneckArgs), vp],

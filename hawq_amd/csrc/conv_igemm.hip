@@ -1447,14 +1447,19 @@ int pick_tile(int M, int Cout, bool dual) {
 bool band_persist_applies(const hawq_conv_args *a);
 int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs_per_cu, void *stream);
 
-// band_v2.hip: the round-5 3x3 kernels (ids after the weight-stationary kernel's two)
+// band_v2.hip: the round-5 3x3 kernels (ids after the weight-stationary kernel's two); gemm_v2.hip: the round-5 streaming 1x1 kernels (last ids)
+int gemm_v2_count(void);
+bool gemm_v2_applies(const hawq_conv_args *a, int v);
+int gemm_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream);
 int band_v2_count(void);
 bool band_v2_applies(const hawq_conv_args *a, int v);
 int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream);
 
-extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count(); }  // the 3x3 kernels are the last ids
+extern "C" int hawq_conv2d_num_tiles(void) { return NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count() + gemm_v2_count(); }  // the special-purpose kernels are the last ids
+extern "C" int hawq_conv2d_num_gemm2_tiles(void) { return gemm_v2_count(); }
+extern "C" int hawq_conv2d_gemm2_first(void) { return NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count() + 1; }
 // + the weight-stationary kernel of band_persist.hip with 1 / 2 workgroups per CU + the round-5 kernels of band_v2.hip
-extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES + 2 + band_v2_count(); }
+extern "C" int hawq_conv2d_num_band_tiles(void) { return NUM_BAND_TILES + 2 + band_v2_count() + gemm_v2_count(); }
 
 extern "C" int hawq_conv2d_num_band2_tiles(void) { return band_v2_count(); }
 extern "C" int hawq_conv2d_band2_tile(const hawq_conv_args *a) {
@@ -1615,6 +1620,11 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         for (int k = 0; k < NUM_BAND_TILES && tile < 0; ++k)
             if (band_applies(kBand[kBandPreference[k]], a)) tile = NUM_TILES + kBandPreference[k];
         HAWQ_REQUIRE(tile >= 0, "hawq_conv2d: in_planar input but no 3x3 band kernel takes this layer");
+    }
+    if (tile >= NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count() && tile < NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count() + gemm_v2_count()) {
+        const int v = tile - (NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count());
+        HAWQ_REQUIRE(gemm_v2_applies(a, v), "hawq_conv2d: tile %d (round-5 1x1 kernel) does not apply to this layer", a->tile);
+        return gemm_v2_launch(a, v, p.k0 == 2, p.dbg, stream);
     }
     if (tile >= NUM_TILES + NUM_BAND_TILES + 2 && tile < NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count()) {
         const int v = tile - (NUM_TILES + NUM_BAND_TILES + 2);

@@ -114,6 +114,10 @@ class _Conv:
             self.w_band = None
             if (self.kh, self.kw, self.stride, self.pad) == (3, 3, 1, 1) and self.w_bits == 8 and self.cin >= 128 and not os.environ.get("HAWQ_NO_BAND2"):
                 self.w_band = torch.from_numpy(packing.pack_w3x3_band(wp, self.cout, self.cin)).to(dev)
+            # ... and the round-5 streaming 1x1 kernels in 128-byte K chunks (hawq_conv_args.wgt_k128 / wgt2_k128)
+            self.w_k128 = None
+            if (self.kh, self.kw, self.pad) == (1, 1, 0) and self.w_bits == 8 and self.cin % 128 == 0 and not os.environ.get("HAWQ_NO_GEMM2"):
+                self.w_k128 = torch.from_numpy(packing.pack_w1x1_k128(wp, self.cout, self.cin)).to(dev)
         self.bias = _i32(self.b_host, dev)
         # exact per-channel bound on |accumulator| -> bit length, for the requant pre-shift check
         amax = max(abs(int(in_range[0])), abs(int(in_range[1]))) if in_range is not None else (128 if in_bits == 8 else 15)
@@ -380,6 +384,8 @@ class IntegerEngine:
             # the same integers from an int8 copy of its weights (the block input never takes a storage format at all)
             c.w8 = torch.from_numpy(packing.pack_conv_weight(c.w_host, 8)).to(self.dev)
         r.wgt, r.bias = (c.w if c.w_bits == 8 else c.w8).data_ptr(), c.bias.data_ptr()
+        if getattr(c, "w_k128", None) is not None:
+            r.wgt_k128 = c.w_k128.data_ptr()   # (for the two-launch form of the pair; ignored by the fused launch)
         r.N, r.H, r.W, r.Cin, r.Cout, r.KH, r.KW, r.stride, r.pad = N, ho, wo, c.cin, c.cout, c.kh, c.kw, c.stride, c.pad
         r.in_bits, r.w_bits = 8, 8
         r.m, r.e, r.ctab = ent['m'].data_ptr(), ent['e'].data_ptr(), ent['ctab'].data_ptr()
@@ -401,6 +407,8 @@ class IntegerEngine:
         C.memmove(C.byref(r1), C.byref(r), C.sizeof(r1))
         r1.in_, r1.in_bits = q.data_ptr(), nxt['a_bits']
         r1.wgt, r1.w_bits = c.w.data_ptr(), c.w_bits
+        if c.w_bits != 8 or nxt['a_bits'] != 8:
+            r1.wgt_k128 = None
         pair = _FusedPair(er, a, r1, self.stream.cuda_stream)
         keep += [out, er, q, r1, pair]
         return pair, out, ob, planar
@@ -652,6 +660,8 @@ class IntegerEngine:
                 a.in_, a.wgt, a.bias = x_in.data_ptr(), c.w.data_ptr(), c.bias.data_ptr()
                 if getattr(c, "w_band", None) is not None and x_bits == 8:
                     a.wgt_band = c.w_band.data_ptr()
+                if getattr(c, "w_k128", None) is not None and x_bits == 8:
+                    a.wgt_k128 = c.w_k128.data_ptr()
                 a.N, a.H, a.W, a.Cin, a.Cout = N, hin, win, c.cin, c.cout
                 a.KH, a.KW, a.stride, a.pad = c.kh, c.kw, c.stride, c.pad
                 a.in_bits, a.w_bits = x_bits, c.w_bits
@@ -692,6 +702,8 @@ class IntegerEngine:
                     if u['resize']:
                         ic = u['ident']
                         a.in2, a.wgt2, a.bias2 = qa.data_ptr(), ic.w.data_ptr(), ic.bias.data_ptr()
+                        if getattr(ic, "w_k128", None) is not None and u['a_bits'] == 8:
+                            a.wgt2_k128 = ic.w_k128.data_ptr()
                         a.H2, a.W2, a.Cin2, a.stride2 = h, w, ic.cin, ic.stride
                         a.in2_bits, a.w2_bits = u['a_bits'], ic.w_bits
                         a.m_id, a.e_id = u['m_id'].data_ptr(), u['e_id'].data_ptr()

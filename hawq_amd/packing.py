@@ -61,6 +61,19 @@ def pack_w3x3_band(w_packed: np.ndarray, cout: int, cin: int) -> np.ndarray:
     return np.ascontiguousarray(w).reshape(-1)
 
 
+def pack_w1x1_k128(w_packed: np.ndarray, cout: int, cin: int) -> np.ndarray:
+    """[Cout][Cin] int8 bytes (pack_conv_weight's layout of a 1x1 conv) -> the stream the round-5 1x1 kernels consume
+    (include/hawq_mi355.h: hawq_conv_args.wgt_k128): [Cout/64][Cin/128][64 rows][128 B], the eight 16-byte slots of row r stored at
+    slot ^ ((r >> 1) & 7).  Same integers, only re-ordered (the C twin is hawq_pack_w1x1_k128)."""
+    assert cout % 64 == 0 and cin % 128 == 0
+    w = np.asarray(w_packed, np.uint8).reshape(cout // 64, 64, cin // 128, 8, 16)       # g, r, ch, slot, byte
+    r = np.arange(64)
+    src_slot = np.arange(8)[None, :] ^ ((r[:, None] >> 1) & 7)                          # stored slot s holds logical slot s ^ sw(r)
+    w = w[:, r[:, None], :, src_slot, :]                                                # -> r, s, g, ch, byte
+    w = w.transpose(2, 3, 0, 1, 4)                                                      # g, ch, r, s, byte
+    return np.ascontiguousarray(w).reshape(-1)
+
+
 def pack_stem_weight(w_int: np.ndarray) -> np.ndarray:
     """[64][3][7][7] integer stem weights -> [64][7][8][4] int8 (kw and c zero padded)."""
     w = np.rint(np.asarray(w_int, np.float64)).astype(np.int64)

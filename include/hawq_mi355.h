@@ -145,25 +145,38 @@ typedef struct hawq_conv_args {
        stream a workgroup consumes - [Cout/64][Cin/64][kh][kw][64 rows][64 B], the 16-byte slots of a row XOR-swizzled - so that every
        LDS-DMA instruction of the weight ring copies one contiguous KiB.  NULL = not provided: those tile ids refuse the layer. */
     const void *wgt_band;
+    /* ABI 5 - the round-5 1x1 kernels (gemm_v2.hip; 1x1 / pad 0 convs with Cin % 128 == 0, int8 operands, NHWC rows): the weights of
+       `wgt` / `wgt2` packed by hawq_pack_w1x1_k128 - [Cout/64][Cin/128][64 rows][128 B], 16-byte slot s of row r at s ^ ((r >> 1) & 7) -
+       so that the K loop walks full 128-byte lines and every weight piece is a contiguous KiB.  NULL = not provided. */
+    const void *wgt_k128;
+    const void *wgt2_k128;
 } hawq_conv_args;
 
 int hawq_conv2d(const hawq_conv_args *args, void *stream);
 int hawq_conv2d_num_tiles(void);
-/* The LAST hawq_conv2d_num_band_tiles() tile ids are the 3x3/stride-1/pad-1 "band" kernels (fast-contract
- * layers only; hawq_conv2d refuses them for any other layer): the band kernels of rounds 1-3, then the weight-stationary persistent
+/* The LAST hawq_conv2d_num_band_tiles() tile ids are special-purpose kernels (fast-contract layers only; hawq_conv2d refuses them
+ * for any layer they are not built for): the 3x3/stride-1/pad-1 "band" kernels of rounds 1-3, then the weight-stationary persistent
  * kernel for Cin == Cout == 64 (int8 in and out, REQUANT, NHWC output) with one / two workgroups per CU, then (ABI 5) the
- * hawq_conv2d_num_band2_tiles() kernels of round 5.  All other ids take any layer. */
+ * hawq_conv2d_num_band2_tiles() 3x3 kernels and the hawq_conv2d_num_gemm2_tiles() streaming 1x1 kernels of round 5.  All other ids
+ * take any layer. */
 int hawq_conv2d_num_band_tiles(void);
 /* 1-based id of the preferred band tile that takes this layer as described (geometry, widths, epilogue,
  * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */
 int hawq_conv2d_band_tile(const hawq_conv_args *args);
-/* ABI 5: the LAST hawq_conv2d_num_band2_tiles() of those ids are the round-5 3x3 kernels (band_v2.hip; need args->wgt_band and
+/* ABI 5: hawq_conv2d_num_band2_tiles() of those ids (the ones in front of the 1x1 kernels) are the round-5 3x3 kernels (band_v2.hip; need args->wgt_band and
  * in_planar == 1; int8 operands, Cin >= 128; REQUANT, or single-branch RESIDUAL on uint16 residuals; int8 NHWC or planar output).  hawq_conv2d_band2_tile: 1-based id of the first of them that takes the layer as described, else 0.
  * hawq_pack_w3x3_band: [Cout][3][3][Cin] int8 (the layout of `wgt`) -> the stream described at hawq_conv_args.wgt_band, on the host
  * (dst and src are host pointers of Cout * 9 * Cin bytes; Cin and Cout multiples of 64). */
 int hawq_conv2d_num_band2_tiles(void);
 int hawq_conv2d_band2_tile(const hawq_conv_args *args);
 int hawq_pack_w3x3_band(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin);
+/* ABI 5: the LAST hawq_conv2d_num_gemm2_tiles() tile ids are the round-5 streaming
+ * 1x1 kernels (need args->wgt_k128 - and wgt2_k128 with a second branch -, NHWC int8 input, fast_tables; REQUANT, RESIDUAL on uint16
+ * residuals, or RESIDUAL with the identity conv as second branch).  hawq_conv2d_gemm2_first(): the 1-based id of the first of them.
+ * hawq_pack_w1x1_k128: [Cout][Cin] int8 -> the stream described at hawq_conv_args.wgt_k128 (host pointers). */
+int hawq_conv2d_num_gemm2_tiles(void);
+int hawq_conv2d_gemm2_first(void);
+int hawq_pack_w1x1_k128(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin);
 
 /* Fused launch of two consecutive layers of the bottleneck graph (q_resnet.py:231-260): the 1x1 expand conv of unit i
  * with its RESIDUAL epilogue (x + identity -> quant_act_int32 -> ReLU -> quant_act of unit i+1) and the 1x1 reduce

@@ -12,8 +12,9 @@ from hawq_amd.quant_utils import requant_table
 L = lib.load()
 rng = np.random.default_rng(0)
 batches = [int(v) for v in sys.argv[1:]] or [64, 128]
-n_all, n_b1, n_b2 = L.hawq_conv2d_num_tiles(), L.hawq_conv2d_num_band_tiles(), L.hawq_conv2d_num_band2_tiles()
-first_band = n_all - n_b2 - n_b1
+n_g2 = L.hawq_conv2d_num_gemm2_tiles()
+n_all, n_b1, n_b2 = L.hawq_conv2d_num_tiles() - n_g2, L.hawq_conv2d_num_band_tiles() - n_g2, L.hawq_conv2d_num_band2_tiles()
+first_band = n_all - n_b1
 planar_out = int(os.environ.get("PLANAR_OUT", "0"))
 shapes = [(56, 64), (28, 128), (14, 256), (7, 512)]
 shapes = [shapes[int(i)] for i in os.environ.get("SHAPES", "0,1,2,3").split(",")]
