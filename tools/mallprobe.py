@@ -89,8 +89,9 @@ def time_it(fn, reps=10):
     return best
 
 
+SIZES = tuple(int(v) for v in os.environ.get("MALL_SIZES", "128,64,32,16").split(","))
 results = {}
-for S in (128, 64, 32, 16):
+for S in SIZES:
     engines = []
     for k in range(128 // S):
         e = IntegerEngine(model, use_graph=False, chains=1)
@@ -106,9 +107,9 @@ for S in (128, 64, 32, 16):
     del engines
     torch.cuda.empty_cache()
 
-print("\n| launch group | " + " | ".join(f"{128 // S} x {S} img" for S in (128, 64, 32, 16)) + " |  (us per 128 images, sequential"
+print("\n| launch group | " + " | ".join(f"{128 // S} x {S} img" for S in SIZES) + " |  (us per 128 images, sequential"
       + (" / two at a time" if "--conc" in sys.argv else "") + ")")
-print("|---|---|---|---|---|")
+print("|---|" + "---|" * len(SIZES))
 for g, _ in GROUPS:
     print(f"| {g} | " + " | ".join(f"{results[(g, S, 1)]:.0f}" + (f" / {results[(g, S, 2)]:.0f}" if (g, S, 2) in results else "")
-                                  for S in (128, 64, 32, 16)) + " |")
+                                  for S in SIZES) + " |")
