@@ -47,7 +47,7 @@ struct B2P {
     int *flags;
     int M, Ho, Wo, Cin, Cout;
     int nsteps, cchunks;
-    int out_planar, q_lo, q_hi;
+    int out_planar, out_bits, q_lo, q_hi;
     int mq, eq, m_id, e_id;
     unsigned in_bytes, wgt_bytes;
     int dbg;
@@ -109,9 +109,38 @@ __device__ __forceinline__ int lds_min4_now(unsigned addr) {   // min of the 4 d
 }
 __device__ __forceinline__ void lds_store_b32(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
+// hawq4 operands (both 4-bit, Cin % 128 == 0): 8 channels per dword, (c0 | c1 << 8 | c2 << 16 | c3 << 24) | (c4 .. c7 likewise) << 4
+// (include/hawq_mi355.h).  A 64-byte slice is then 128 channels; the packed bytes travel through LDS untouched and every 16-byte
+// fragment (32 channels) feeds TWO MFMA K-steps after unpacking in registers - activations zero-extended, weights as value * 16 (the
+// nibble moved to the top of its byte: sign for free), the sums shifted back by 4 once, which is exact.
+template <bool WEIGHT>
+__device__ __forceinline__ v4i b2_unpack16(unsigned x0, unsigned x1) {
+    v4i r;
+    if (WEIGHT) {
+        r.x = (int)((x0 << 4) & 0xF0F0F0F0u), r.y = (int)(x0 & 0xF0F0F0F0u), r.z = (int)((x1 << 4) & 0xF0F0F0F0u), r.w = (int)(x1 & 0xF0F0F0F0u);
+    } else {
+        r.x = (int)(x0 & 0x0F0F0F0Fu), r.y = (int)((x0 >> 4) & 0x0F0F0F0Fu), r.z = (int)(x1 & 0x0F0F0F0Fu), r.w = (int)((x1 >> 4) & 0x0F0F0F0Fu);
+    }
+    return r;
+}
+// this lane's 16 consecutive requantised channels (4 dwords of 4 bytes each, already clamped) of pixel m, first channel ch: int8 or hawq4,
+// NHWC rows or channel-group planes (16 / 32 channels per 16-byte unit)
+__device__ __forceinline__ void b2_store_q(const B2P &p, const int (&w)[4], int m, int ch) {
+    if (p.out_bits == 8) {
+        const v4i ww = {w[0], w[1], w[2], w[3]};
+        char *dst = p.out_planar ? p.out + ((size_t)(ch >> 4) * p.M + m) * 16 : p.out + (size_t)m * p.Cout + ch;
+        *reinterpret_cast<v4i *>(dst) = ww;
+    } else {   // bytes hold values 0 .. 15: channels 4k .. 4k+3 in w[k]; low nibbles = channels 0-3 of an 8-group, high = 4-7
+        const v2i ww = {w[0] | (w[1] << 4), w[2] | (w[3] << 4)};
+        char *dst = p.out_planar ? p.out + ((size_t)(ch >> 5) * p.M + m) * 16 + ((ch >> 4) & 1) * 8 : p.out + (((size_t)m * p.Cout + ch) >> 1);
+        *reinterpret_cast<v2i *>(dst) = ww;
+    }
+}
+
 // EPI: HAWQ_EPI_REQUANT, or HAWQ_EPI_RESIDUAL (single branch, uint16 residuals: the second conv of a basic block).
 // MODE: 0 = tie-free tables, 2 = exact-tie correction on every requant (fast_tables bit 2).
-template <class C, int EPI, int MODE>
+// NIB: both operands hawq4.
+template <class C, int EPI, int MODE, bool NIB>
 __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool prof = HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf;
@@ -273,9 +302,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         _Pragma("unroll") for (int c = 0; c < 2; ++c) pin(wf[KW][c]);                                  \
         _Pragma("unroll") for (int q = 0; q < C::PT; ++q) pin(af[KW][q]);                              \
         if (!HAWQ_DBG_BIT(p.dbg, 2)) {                                                                \
-            _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                         \
-                _Pragma("unroll") for (int c = 0; c < 2; ++c)                                         \
-                    acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[KW][c], af[KW][q], acc[c][q], 0, 0, 0); \
+            if constexpr (NIB) {                                                                      \
+                _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                    \
+                    v4i w8[2], a8[C::PT];                                                             \
+                    _Pragma("unroll") for (int c = 0; c < 2; ++c) w8[c] = b2_unpack16<true>((unsigned)wf[KW][c][2 * hf], (unsigned)wf[KW][c][2 * hf + 1]); \
+                    _Pragma("unroll") for (int q = 0; q < C::PT; ++q) a8[q] = b2_unpack16<false>((unsigned)af[KW][q][2 * hf], (unsigned)af[KW][q][2 * hf + 1]); \
+                    _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                 \
+                        _Pragma("unroll") for (int c = 0; c < 2; ++c)                                 \
+                            acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w8[c], a8[q], acc[c][q], 0, 0, 0); \
+                }                                                                                     \
+            } else {                                                                                  \
+                _Pragma("unroll") for (int q = 0; q < C::PT; ++q)                                     \
+                    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                     \
+                        acc[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[KW][c], af[KW][q], acc[c][q], 0, 0, 0); \
+            }                                                                                         \
         }                                                                                             \
     }
     constexpr int NF = 2 + C::PT;   // fragment reads per tap
@@ -373,7 +413,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
                     const v4i v = *reinterpret_cast<const v4i *>(src + ((qq * 2 + c) * 4 + i) * 1024);
                     const v16i &a = acc[c][gg * C::HQ + qq];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sum[c][qq][4 * i + j] = a[4 * i + j] + v[j];
+                    for (int j = 0; j < 4; ++j) sum[c][qq][4 * i + j] = NIB ? (a[4 * i + j] + v[j]) >> 4 : a[4 * i + j] + v[j];   // (weights were value * 16)
                 }
     };
     if (g == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
@@ -404,12 +444,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
 #pragma unroll
             for (int qq = 0; qq < C::HQ; ++qq) {
                 const int m = m0 + wave_m * (32 * C::PT) + (g * C::HQ + qq) * 32 + l31;
-                const v4i ww = {w[qq][0], w[qq][1], w[qq][2], w[qq][3]};
-                if (m < p.M && !HAWQ_DBG_BIT(p.dbg, 8)) {
-                    char *dst = p.out_planar ? p.out + ((size_t)((c0 >> 4) + 2 * c + h) * p.M + m) * 16
-                                             : p.out + (size_t)m * p.Cout + c0 + lch;
-                    *reinterpret_cast<v4i *>(dst) = ww;
-                }
+                if (m < p.M && !HAWQ_DBG_BIT(p.dbg, 8)) b2_store_q(p, w[qq], m, c0 + lch);
             }
         }
     }
@@ -461,12 +496,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
                         const v4i ra = {rp[qq][0], rp[qq][1], rp[qq][2], rp[qq][3]}, rb = {rp[qq][4], rp[qq][5], rp[qq][6], rp[qq][7]};
                         dst[0] = ra, dst[1] = rb;
                     }
-                    if (p.out) {
-                        const v4i ww = {w[qq][0], w[qq][1], w[qq][2], w[qq][3]};
-                        char *dst = p.out_planar ? p.out + ((size_t)((c0 >> 4) + 2 * c + h) * p.M + m) * 16
-                                                 : p.out + (size_t)m * p.Cout + c0 + lch;
-                        *reinterpret_cast<v4i *>(dst) = ww;
-                    }
+                    if (p.out) b2_store_q(p, w[qq], m, c0 + lch);
                 }
             }
         }
@@ -487,9 +517,10 @@ using V256 = V2Cfg<2, 4, 4, 5, 384, 3>;    // 256 px x 64 ch: 8 MFMA waves + 4 p
 constexpr int NUM_V2 = 2;
 
 typedef void (*V2Fn)(const B2P);
-struct V2Info { V2Fn fn[2][2]; int bm, band_px, lds, nt, tight; };   // fn[residual][exact-tie]
-#define V2_ENTRY(CFG) {{{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2>}, \
-                        {conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 0>, conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 2>}}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
+struct V2Info { V2Fn fn[2][2][2]; int bm, band_px, lds, nt, tight; };   // fn[hawq4][residual][exact-tie]
+#define V2_FNS(CFG, N) {{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0, N>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2, N>}, \
+                        {conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 0, N>, conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 2, N>}}
+#define V2_ENTRY(CFG) {{V2_FNS(CFG, false), V2_FNS(CFG, true)}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
 const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V256)};
 
 }  // namespace
@@ -518,13 +549,16 @@ bool band_v2_applies(const hawq_conv_args *a, int v) {
     const V2Info &vi = kV2[v];
     const long long M = (long long)a->N * a->H * a->W;
     const int band_len = vi.bm + 2 * a->W + 2 + 7;   // pixels m0 - Wo - 1 .. m0 + BM + Wo, start rounded down to a line
-    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8) ||
+    const bool qout_ok = a->out_bits == 8 || (a->out_bits == 4 && a->q_lo >= 0 && a->q_hi <= 15 && a->Cout % 32 == 0);
+    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && qout_ok && (a->out_bits == 8 || a->relu || a->q_lo >= 0)) ||
                         (a->epilogue == HAWQ_EPI_RESIDUAL && a->res_in && a->res_in_bits == 16 && (!a->res_out || (a->res_out_bits == 16 && a->flags)) &&
-                         !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || a->out_bits == 8));
+                         !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || qout_ok));
+    const bool nib = a->in_bits == 4 && a->w_bits == 4;
+    const int rowb = nib ? a->Cin >> 1 : a->Cin;   // bytes per pixel
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
-           a->in_planar == 1 && epi_ok && a->in_bits == 8 && a->w_bits == 8 &&
-           a->ctab && (a->in_pitch == 0 || a->in_pitch == a->Cin) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
-           band_len <= vi.band_px - 4 && a->Cin / 64 * 3 >= 6 && M * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin * 9 < (1ll << 31);
+           a->in_planar == 1 && epi_ok && ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) &&
+           a->ctab && (a->in_pitch == 0 || a->in_pitch == rowb) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
+           band_len <= vi.band_px - 4 && rowb / 64 * 3 >= 6 && M * rowb < (1ll << 31) && (long long)a->Cout * rowb * 9 < (1ll << 31);
 }
 
 int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream) {
@@ -533,12 +567,14 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     p.in = (const char *)a->in, p.wgt = (const char *)a->wgt_band, p.ctab = a->ctab, p.out = (char *)a->out_q;
     p.res_in = (const char *)a->res_in, p.res_out = (char *)a->res_out, p.flags = a->flags;
     p.M = a->N * a->H * a->W, p.Ho = a->H, p.Wo = a->W, p.Cin = a->Cin, p.Cout = a->Cout;
-    p.cchunks = a->Cin >> 6, p.nsteps = 3 * p.cchunks;
-    p.out_planar = a->out_planar;
+    const bool nib = a->in_bits == 4;
+    const int rowb = nib ? a->Cin >> 1 : a->Cin;
+    p.cchunks = rowb >> 6, p.nsteps = 3 * p.cchunks;
+    p.out_planar = a->out_planar, p.out_bits = a->out_bits;
     p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
     p.mq = a->mq, p.eq = a->eq, p.m_id = a->m_id_scalar, p.e_id = a->e_id_scalar;
     if (a->epilogue == HAWQ_EPI_RESIDUAL && !a->out_q) p.mq = 0, p.eq = 33;   // no next QuantAct: a harmless table
-    p.in_bytes = (unsigned)((long long)p.M * a->Cin), p.wgt_bytes = (unsigned)((long long)a->Cout * a->Cin * 9);
+    p.in_bytes = (unsigned)((long long)p.M * rowb), p.wgt_bytes = (unsigned)((long long)a->Cout * rowb * 9);
     p.dbg = dbg;
     static long long *dbg_dev = nullptr;
     if (HAWQ_DBG_BIT(dbg, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 8 * sizeof(long long));
@@ -546,12 +582,12 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     static const bool attrs = [] {
         bool good = true;
         for (const V2Info &i : kV2)
-            for (int k = 0; k < 4; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k >> 1][k & 1], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+            for (int k = 0; k < 8; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k >> 2][(k >> 1) & 1][k & 1], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
         return good;
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv2d: hipFuncSetAttribute failed for the round-5 3x3 kernels");
     const int grid = ((p.M + vi.bm - 1) / vi.bm) * (p.Cout >> 6);
-    hipLaunchKernelGGL(vi.fn[a->epilogue == HAWQ_EPI_RESIDUAL ? 1 : 0][exact_tie ? 1 : 0], dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(vi.fn[nib ? 1 : 0][a->epilogue == HAWQ_EPI_RESIDUAL ? 1 : 0][exact_tie ? 1 : 0], dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {   // experiment hook (synchronises!)
         long long hb[6];

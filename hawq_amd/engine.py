@@ -112,8 +112,10 @@ class _Conv:
             self.w = torch.from_numpy(wp).to(dev)
             # the round-5 3x3 kernels stream the same integers in tile order (include/hawq_mi355.h: hawq_conv_args.wgt_band)
             self.w_band = None
-            if (self.kh, self.kw, self.stride, self.pad) == (3, 3, 1, 1) and self.w_bits == 8 and self.cin >= 128 and not os.environ.get("HAWQ_NO_BAND2"):
-                self.w_band = torch.from_numpy(packing.pack_w3x3_band(wp, self.cout, self.cin)).to(dev)
+            rowb = self.cin * self.w_bits // 8   # bytes of a filter tap (hawq4: two channels per byte, Cin % 128 == 0 for the nibble kernels)
+            if ((self.kh, self.kw, self.stride, self.pad) == (3, 3, 1, 1) and rowb >= 128 and rowb % 64 == 0 and (self.w_bits == 8 or self.cin % 128 == 0)
+                    and not os.environ.get("HAWQ_NO_BAND2")):
+                self.w_band = torch.from_numpy(packing.pack_w3x3_band(wp, self.cout, rowb)).to(dev)
             # ... and the round-5 streaming 1x1 kernels in 128-byte K chunks (hawq_conv_args.wgt_k128 / wgt2_k128)
             self.w_k128 = None
             if (self.kh, self.kw, self.pad) == (1, 1, 0) and self.w_bits == 8 and self.cin % 128 == 0 and not os.environ.get("HAWQ_NO_GEMM2"):
@@ -658,7 +660,7 @@ class IntegerEngine:
                 ho, wo = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
                 a = _lib.ConvArgs()
                 a.in_, a.wgt, a.bias = x_in.data_ptr(), c.w.data_ptr(), c.bias.data_ptr()
-                if getattr(c, "w_band", None) is not None and x_bits == 8:
+                if getattr(c, "w_band", None) is not None and x_bits == c.w_bits:
                     a.wgt_band = c.w_band.data_ptr()
                 if getattr(c, "w_k128", None) is not None and x_bits == 8:
                     a.wgt_k128 = c.w_k128.data_ptr()

@@ -23,16 +23,16 @@ def _ids(lib):
     return list(range(n - ng2 - nb2 + 1, n - ng2 + 1))
 
 
-def _applies(bm, band_px, w, cin):
-    return bm + 2 * w + 9 <= band_px - 4 and cin >= 128
+def _applies(bm, band_px, w, cin, bits=8):
+    return bm + 2 * w + 9 <= band_px - 4 and cin * bits // 8 >= 128 and (bits == 8 or cin % 128 == 0)
 
 
-def _args(lib, x, wt, b, tile):
+def _args(lib, x, wt, b, tile, bits=8):
     from hawq_amd.packing import pack_conv_weight, pack_w3x3_band
-    a, keep = conv_args(lib, x, wt, b, 1, 1, 8, 8, tile=tile)
+    a, keep = conv_args(lib, x, wt, b, 1, 1, bits, bits, tile=tile)
     cout, cin = wt.shape[0], wt.shape[1]
-    keep['wb'] = dev(pack_w3x3_band(pack_conv_weight(wt, 8), cout, cin))
-    keep['xp'] = dev(to_planar(pack_act(x, 8)))
+    keep['wb'] = dev(pack_w3x3_band(pack_conv_weight(wt, bits), cout, cin * bits // 8))
+    keep['xp'] = dev(to_planar(pack_act(x, bits)))
     a.wgt_band, a.in_, a.in_planar = keep['wb'].data_ptr(), keep['xp'].data_ptr(), 1
     return a, keep
 
@@ -181,3 +181,39 @@ def test_band2_full_size_equals_the_band_kernels(lib, name, shape):
         assert torch.equal(out, ref), tile
         ran += 1
     assert ran >= 1
+
+
+@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (5, 14, 14, 256, 256), (9, 7, 7, 512, 128), (2, 9, 30, 256, 64), (2, 14, 14, 128, 64)])
+@pytest.mark.parametrize("mode", [1, 5])
+def test_band2_hawq4_operands_and_outputs(lib, orc, shape, mode):
+    """W4A4 layers (both operands hawq4 nibbles, Cin % 128 == 0; Cin = 128 is a single 64-byte slice and is refused: the kernels want
+    two): int8 and hawq4 outputs, NHWC and planar; and a hawq4 output from int8 operands (mixed schedules)."""
+    from hawq_amd.packing import pack_ctab
+    from hawq_amd.quant_utils import tables_are_fast
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(h * 100 + w + cin + 4)
+    for bits in (4, 8):
+        x, wt, b = make_conv(rng, n, h, w, cin, cout, 3, bits, bits)
+        acc = orc.conv2d(x, wt, b, 1, 1)
+        m, e = rand_tables(rng, cout, 2e-5 if bits == 8 else 2e-3, 3e-4 if bits == 8 else 2e-2)
+        assert tables_are_fast(m, e, int(np.abs(acc).max()).bit_length() + 1)
+        for tile, (bm, band_px) in zip(_ids(lib), GEOM2):
+            a, keep = _args(lib, x, wt, b, tile, bits)
+            keep.update(ctab=dev(pack_ctab(b, m, e)), m=dev(m), e=dev(e))
+            a.epilogue, a.relu, a.m, a.e, a.ctab, a.fast_tables = lib.EPI_REQUANT, 1, keep['m'].data_ptr(), keep['e'].data_ptr(), keep['ctab'].data_ptr(), mode
+            for out_bits, (lo, hi) in ((8, (-128, 127)), (4, (0, 15))):
+                if bits == 8 and out_bits == 8:
+                    continue   # test_band2_requant
+                out = torch.zeros(acc.size * out_bits // 8, dtype=torch.uint8, device='cuda')
+                a.out_q, a.out_bits, a.q_lo, a.q_hi = out.data_ptr(), out_bits, lo, hi
+                if not _applies(bm, band_px, w, cin, bits):
+                    a.out_planar = 0
+                    assert lib.load().hawq_conv2d(C.byref(a), None) != 0
+                    continue
+                ref = odyadic(orc, np.maximum(acc, 0), m, e, (lo, hi))
+                for outp in (0, 1):
+                    a.out_planar = outp
+                    out.zero_()
+                    lib.call("hawq_conv2d", C.byref(a), stream())
+                    got = from_planar(out, (n, h, w, cout), out_bits) if outp else unpack_q(out, (n, h, w, cout), out_bits)
+                    assert np.array_equal(got, ref), (bits, tile, out_bits, outp)
