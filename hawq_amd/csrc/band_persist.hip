@@ -25,7 +25,11 @@ namespace {
 struct BPP {
     const uint8_t *in, *wgt;
     const int32_t *ctab;
-    uint8_t *out;
+    uint8_t *out;              // int8: NHWC [M][64] or (round 5) planes [4][M][16 B]; null = none (RESIDUAL)
+    const uint16_t *res_in;    // RESIDUAL (round 5): [M][64] uint16
+    uint16_t *res_out;         // [M][64] uint16 or null
+    int *flags;
+    int out_planar, mq, eq, m_id, e_id;
     int M, rows_total, Ho, Wo;
     int in_planar;   // activations as channel-group planes [4][M][16 B] (hawq_conv_args.in_planar)
     float rcp_wo, rcp_ho;
@@ -58,8 +62,10 @@ __device__ __forceinline__ int fdiv(int m, int d, float r) {
     return g;
 }
 
-template <bool TIE>
-__global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
+// RES (round 5): RESIDUAL epilogue - the second 3x3 conv of a ResNet18/34 stage-1 basic block (q_resnet.py:300-316): uint16 residual in and
+// out (quant_utils.py:415-456), the next block's QuantAct as int8 output.
+template <bool TIE, bool RES = false>
+__global__ __launch_bounds__(NT, RES ? 3 : 4) void band_persist_kernel(const BPP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MODE = TIE ? 2 : 0;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -131,7 +137,6 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) wofs[c][ks] = lds_addr(smem + OFF_W) + lds_off(c * 32 + cperm(l31), 2 * ks + h);
     const unsigned band0 = lds_addr(smem + OFF_BAND);
-    char *stage = smem + OFF_STAGE + wave * 2048;
     const char *ctb = smem + OFF_CTAB;
     BP_STAMP(0)
     __builtin_amdgcn_s_barrier();   // A(first tile)
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
         __builtin_amdgcn_s_barrier();   // B(tile): the band may be refilled
         // ------------------------------------------------------------------ epilogue: requant, private transposition, 64-byte rows
         int w[2][2][4];   // [pixel tile][channel tile][4 channels each]
+        if constexpr (!RES) {
         // the kernel is bound by the ISSUE of this requantisation (profiles/r02_band_persist.md): with all pre-shifts zero (the
         // usual case, a wave-uniform flag) the table word IS the shift amount - no field extraction, no pre-shift: 3.75 instead
         // of 5.75 VALU instructions per output.  Uniform branch between two instantiations of the same code
@@ -225,6 +231,80 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
                 }
         };
         requant_all(std::false_type{});   // (the all-k-zero form under a wave-uniform branch measured neutral in the forward: not kept)
+        } else {
+            // RESIDUAL: o = ReLU(requant(acc + bias) + requant(identity)) un-clamped -> uint16 (sticky overflow flag); q = next QuantAct of o.
+            // A lane owns 16 consecutive channels of a pixel = 32 contiguous bytes of the residual rows: loaded and stored from registers
+            const DyNt dids = dynt_prepare(p.m_id, p.e_id), dq = dynt_prepare(p.mq, p.eq);   // (scalars: this kernel has no registers to spare)
+            const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);
+            unsigned oor = 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + wave * 64 + q * 32 + l31, mr = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    v4i rin[2];
+                    {
+                        const v4i *rp = reinterpret_cast<const v4i *>(p.res_in + (size_t)mr * 64 + c * 32 + h * 16);
+                        rin[0] = rp[0], rin[1] = rp[1];
+                    }
+                    int rpk[8], wq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned w0 = (unsigned)rin[g >> 1][(g & 1) * 2], w1 = (unsigned)rin[g >> 1][(g & 1) * 2 + 1];
+                        const int idin[4] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+                        int o[4], qv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const v4i e = *reinterpret_cast<const v4i *>(ctb + (c * 32 + h * 16 + 4 * g + j) * 16);
+                            DyNt dm;
+                            dm.m = e.x, dm.s = e.y & 31, dm.k = e.y >> 8;
+                            dm.add = (long long)(((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z);
+                            const int a = dyadic_mode<MODE>(acc[c][q][4 * g + j], dm);
+                            const int b = dyadic_mode<MODE == 2 ? 2 : 0>(idin[j], dids);
+                            o[j] = max(a + b, 0);                  // no clamp: quant_utils.py:456
+                            qv[j] = dyadic_mode<MODE>(o[j], dq);   // o >= 0, m >= 0: q >= 0; clamped from above in the pack
+                        }
+                        if (m < p.M) oor |= (unsigned)(o[0] | o[1]) | (unsigned)(o[2] | o[3]);
+                        rpk[2 * g] = pack2_u16_sat(o[0], o[1]);
+                        rpk[2 * g + 1] = pack2_u16_sat(o[2], o[3]);
+                        wq[g] = pack4_min(qv[0], qv[1], qv[2], qv[3], qhi2);
+                    }
+                    if (m < p.M && p.res_out) {
+                        v4i *dst = reinterpret_cast<v4i *>(p.res_out + (size_t)m * 64 + c * 32 + h * 16);
+                        const v4i ra = {rpk[0], rpk[1], rpk[2], rpk[3]}, rb = {rpk[4], rpk[5], rpk[6], rpk[7]};
+                        dst[0] = ra, dst[1] = rb;
+                    }
+                    const v4i ww = {wq[0], wq[1], wq[2], wq[3]};
+                    if (p.out != nullptr && p.out_planar) {
+                        if (m < p.M) *reinterpret_cast<v4i *>((char *)p.out + ((size_t)(2 * c + h) * p.M + m) * 16) = ww;
+                    } else if (p.out != nullptr) {
+                        *reinterpret_cast<v4i *>(smem + OFF_STAGE + wave * 2048 + lds_off(l31, 2 * c + h)) = ww;
+                    }
+                }
+                if (p.out != nullptr && !p.out_planar) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {   // 16 pixel rows x 64 B per instruction: 1 KiB contiguous
+                        const int row = i * 16 + (lane >> 2), mm = m0 + wave * 64 + q * 32 + row;
+                        const v4i d = *reinterpret_cast<const v4i *>(smem + OFF_STAGE + wave * 2048 + row * 64 + ((lane & 3) << 4));
+                        if (mm < p.M) *reinterpret_cast<v4i *>((char *)p.out + (size_t)mm * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4)) = d;
+                    }
+                }
+            }
+            if ((oor >> 16) != 0 && p.res_out) atomicOr(p.flags, 1);
+        }
+        if (RES) {
+        } else if (p.out != nullptr && p.out_planar) {   // planes [4][M][16 B]: a lane's 16 channels are one unit; 32 lanes = 512 contiguous bytes
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + wave * 64 + q * 32 + l31;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const v4i ww = {w[q][c][0], w[q][c][1], w[q][c][2], w[q][c][3]};
+                    if (m < p.M) *reinterpret_cast<v4i *>((char *)p.out + ((size_t)(2 * c + h) * p.M + m) * 16) = ww;
+                }
+            }
+        } else if (p.out != nullptr) {
+        char *stage = smem + OFF_STAGE + wave * 2048;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
 #pragma unroll
@@ -239,6 +319,7 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
                 if (m < p.M) *reinterpret_cast<v4i *>((char *)p.out + (size_t)m * 64 + (((lane & 3) ^ ((row >> 2) & 3)) << 4)) = d;
             }
         }
+        }
         BP_STAMP(3)
         __builtin_amdgcn_s_barrier();   // A(next tile): its band has landed
         BP_STAMP(4)
@@ -252,9 +333,12 @@ __global__ __launch_bounds__(NT, 2) void band_persist_kernel(const BPP p) {
 
 bool band_persist_applies(const hawq_conv_args *a) {
     const int wo = a->W, band_rows = (BM + wo - 1) / wo + 1 + 2;
+    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8) ||
+                        (a->epilogue == HAWQ_EPI_RESIDUAL && a->res_in && a->res_in_bits == 16 && (!a->res_out || (a->res_out_bits == 16 && a->flags)) &&
+                         !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || a->out_bits == 8));   // (round 5)
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 &&
-           a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && a->in_bits == 8 && a->w_bits == 8 && a->Cin == 64 &&
-           a->Cout == 64 && !a->out_planar && a->ctab && band_rows * (wo + 2) <= ZP && (a->in_pitch == 0 || a->in_pitch == 64) &&
+           epi_ok && a->in_bits == 8 && a->w_bits == 8 && a->Cin == 64 &&
+           a->Cout == 64 && a->ctab && band_rows * (wo + 2) <= ZP && (a->in_pitch == 0 || a->in_pitch == 64) &&
            (a->out_pitch == 0 || a->out_pitch == 64) &&
            (long long)a->N * a->H * a->W < (1ll << 23);
 }
@@ -264,6 +348,9 @@ bool band_persist_applies(const hawq_conv_args *a) {
 int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs_per_cu, void *stream) {
     BPP p;
     p.in = (const uint8_t *)a->in, p.wgt = (const uint8_t *)a->wgt, p.ctab = a->ctab, p.out = (uint8_t *)a->out_q;
+    const bool res = a->epilogue == HAWQ_EPI_RESIDUAL;
+    p.res_in = (const uint16_t *)a->res_in, p.res_out = (uint16_t *)a->res_out, p.flags = a->flags, p.out_planar = a->out_planar;
+    p.mq = a->out_q && res ? a->mq : 0, p.eq = a->out_q && res ? a->eq : 33, p.m_id = a->m_id_scalar, p.e_id = res ? a->e_id_scalar : 33;
     p.M = a->N * a->H * a->W, p.rows_total = a->N * a->H, p.Ho = a->H, p.Wo = a->W;
     p.in_planar = a->in_planar;
     p.rcp_wo = 1.0f / (float)a->W, p.rcp_ho = 1.0f / (float)a->H;
@@ -280,10 +367,16 @@ int band_persist_launch(const hawq_conv_args *a, int exact_tie, int dbg, int wgs
     }();
     HAWQ_REQUIRE(n_cu > 0, "hawq_conv2d: cannot read the CU count of the device");
     static const bool attrs = hipFuncSetAttribute((const void *)band_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
-                              hipFuncSetAttribute((const void *)band_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+                              hipFuncSetAttribute((const void *)band_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+                              hipFuncSetAttribute((const void *)band_persist_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess &&
+                              hipFuncSetAttribute((const void *)band_persist_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
     HAWQ_REQUIRE(attrs, "hawq_conv2d: hipFuncSetAttribute failed for the weight-stationary 3x3 kernel");
     const int grid = p.ntiles < wgs_per_cu * n_cu ? p.ntiles : wgs_per_cu * n_cu;
-    if (exact_tie)
+    if (res && exact_tie)
+        hipLaunchKernelGGL((band_persist_kernel<true, true>), dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    else if (res)
+        hipLaunchKernelGGL((band_persist_kernel<false, true>), dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
+    else if (exact_tie)
         hipLaunchKernelGGL(band_persist_kernel<true>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(band_persist_kernel<false>, dim3(grid), dim3(NT), LDS_BYTES, (hipStream_t)stream, p);
