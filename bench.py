@@ -301,6 +301,42 @@ def launch_model(name, rows, batch):
     return byt, mac
 
 
+def dominant_kernel(eng, args, rows):
+    """The rocprof kernel that takes the largest share of the forward, from the COMMITTED profile passes of this workload
+    (tools/profile_round.sh -> tools/dominant_kernel.py -> profiles/dominant_kernel.json: rocprof name, launches per forward, average
+    duration, matrix-pipe busy fraction), plus - computed here from THIS run's plan - the bytes the fused plan moves for the
+    launches that run that kernel, against 8 TB/s over the profiled duration.  None when no profile of the workload is committed."""
+    from hawq_amd import _lib, roofline
+    try:
+        with open(os.path.join(ROOT, "profiles", "dominant_kernel.json")) as fh:
+            rec = json.load(fh).get(f"{args.arch}_{args.scheme}_b{args.batch}")
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None
+    L = _lib.load()
+    n, nb, nb2, ng2 = (L.hawq_conv2d_num_tiles(), L.hawq_conv2d_num_band_tiles(), L.hawq_conv2d_num_band2_tiles(), L.hawq_conv2d_num_gemm2_tiles())
+    first_special = n - nb + 1                       # 1-based tile ids: generic | band (rounds 1-4) | persistent band | band v2 | streaming 1x1
+    fam = {"conv3x3_v2_kernel": range(n - ng2 - nb2 + 1, n - ng2 + 1), "gemm1x1_v2_kernel": range(n - ng2 + 1, n + 1),
+           "band_persist_kernel": range(n - ng2 - nb2 - 1, n - ng2 - nb2 + 1), "conv3x3_band_kernel": range(first_special, n - ng2 - nb2 - 1),
+           "conv_kernel": range(1, first_special)}
+    ids = next((r for k, r in fam.items() if k in rec["rocprof_name"]), None)
+    fused = {p.split("+")[0] for p in getattr(eng, "er_choice", {}) if eng.er_choice[p]}
+    chains = max(1, getattr(eng, "chains", 1))
+    if ids is not None and rows:
+        names = [k for k, t in eng.tile_choice.items() if t in ids and k.split("+")[0] not in fused]
+        byt = sum(launch_model(k, rows, args.batch // chains)[0] for k in names)
+        mac = sum(launch_model(k, rows, args.batch // chains)[1] for k in names)
+        t = len(names) * rec["avg_us"] * 1e-6
+        if names and t > 0:
+            rec = dict(rec, launches_in_this_plan_per_chain=len(names), plan_bytes_of_those_launches=int(byt),
+                       hbm_frac_plan_bytes=round(byt / t / 1e9 / roofline.HBM_PEAK_GBS, 4),
+                       mfma_frac_plan_macs=round(2 * mac / t / (roofline.MFMA_I8_PEAK_TOPS * 1e12), 4),
+                       note="fractions = this plan's bytes / MACs for the launches on that kernel over launches x the profiled average duration "
+                            "(the profile ran the recorded plan with its concurrent sub-batch chains, so the duration includes their contention)")
+    return rec
+
+
 def write_per_op(path, ops, rows, batch):
     """Per-launch table: measured ms vs the fused plan's byte / MAC model of the layers each launch covers."""
     lines = ["| launch | ms | plan MB | GB/s | % of 8 TB/s | GMAC | TOPS |", "|---|---|---|---|---|---|---|"]
@@ -578,6 +614,7 @@ def main():
                          "plan_floor_ms": round(floor_ms, 4), "plan_floor_ratio": round(gpu_ms / floor_ms, 3),
                          "mfma_frac": round(mfma_frac, 4)},
         }
+        out["roofline"]["dominant_kernel"] = dominant_kernel(eng, args, plan_rows(args.arch, args.scheme) if args.arch in roofline.ARCH else {})
         if world > 1:
             out["weak"], out["strong"] = runs["weak"], runs.get("strong")
         if (not args.no_extra or args.per_op) and world == 1:
@@ -610,7 +647,14 @@ def main():
         # the same workload fed with uint8 NHWC images: table look-up input quantiser, 19 MB instead of
         # 77 MB of input per batch; logits are bit-identical to the fp32-tensor path (tests/test_gpu_network.py)
         xu8 = torch.randint(0, 256, (args.batch, 224, 224, 3), dtype=torch.uint8, device=dev)
-        eng.forward_uint8(xu8)
+        # parity of this line: the same images as the fp32 tensor the reference's host pipeline builds (ToTensor + Normalize,
+        # quant_train.py:432-440, on the CPU in fp32) through the timed engine - whose fp32 path the oracle fixture pins above
+        mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        t32 = xu8.cpu().permute(0, 3, 1, 2).to(torch.float32).div(255)
+        t32 = t32.sub_(torch.tensor(mean).view(1, 3, 1, 1)).div_(torch.tensor(std).view(1, 3, 1, 1))
+        ref_u8 = eng(t32.to(dev)).clone()
+        u8_equal = bool(torch.equal(eng.forward_uint8(xu8, mean, std), ref_u8))
+        del t32, ref_u8
         with torch.cuda.stream(eng.stream):   # warm-up: the GPU idled (and clocked down) during the CPU baseline
             for _ in range(10):
                 eng.run_resident(u8=True)
@@ -621,11 +665,12 @@ def main():
                 eng.run_resident(u8=True)
         torch.cuda.synchronize()
         extra[f"{args.arch}_{args.scheme}_b{args.batch}_uint8_input"] = {
-            "images_per_s": round(args.batch * n2 / (time.perf_counter() - t0), 1)}
+            "images_per_s": round(args.batch * n2 / (time.perf_counter() - t0), 1),
+            "gpu_logits_bit_equal": u8_equal, "parity_against": "the same images as normalised fp32 tensor through the timed (oracle-checked) engine"}
         extra["rccl_world1_gather_ok"] = rccl_world1_selfcheck(dev, eng.logits)
         del eng, model, xu8
         torch.cuda.empty_cache()
-        for arch, scheme in (("resnet50", "uniform4"), ("resnet50", "bops_0.5"), ("resnet18", "uniform8")):
+        for arch, scheme in (("resnet50", "uniform4"), ("resnet50", "bops_0.5"), ("resnet18", "uniform8"), ("resnet101", "uniform8"), ("resnet50b", "uniform8")):
             if (arch, scheme) == (args.arch, args.scheme):
                 continue
             m2, e2, x2 = setup_workload(arch, scheme, args.batch, dev, seed=1, plans=plans)

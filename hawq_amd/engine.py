@@ -436,6 +436,9 @@ class IntegerEngine:
         when it was left open)."""
         if x_view is None:
             self._plan_on = bool(self.plan) and int(self.plan.get("batch", -1)) == N and not self.keep_acc
+            if not self._plan_on and hasattr(self, "chains_req"):
+                # a batch shape the plan was not recorded for: the chain count a replay of ANOTHER shape left behind does not carry over
+                self.chains = max(1, self.chains_req)
         if x_view is None and self._plan_on:
             try:
                 if int(self.plan.get("num_conv_tiles", -1)) != int(_lib.load().hawq_conv2d_num_tiles()):
@@ -489,8 +492,17 @@ class IntegerEngine:
         while the batch shape it was recorded for is being built (`_plan_on`; the chains of a multi-chain engine inherit it), else
         the measurement switches HAWQ_CHAINS / HAWQ_TILES / HAWQ_ER_TILES / HAWQ_ER_SPLIT_TILES, else None (tune)."""
         pl = getattr(self, "plan", None)
-        if pl and getattr(self, "_plan_on", False) and pl.get(key) not in (None, ""):
-            return str(pl[key])
+        if pl and getattr(self, "_plan_on", False):
+            # chains whose tuned choices differ (uneven sub-batches, layers only one tile takes) are recorded one by one
+            per = pl.get("per_chain")
+            i = getattr(self, "_chain_index", None)
+            if per and i is not None and key != "chains":
+                if i >= len(per):
+                    raise StalePlan(f"the recorded plan lists {len(per)} chains")
+                if per[i].get(key) not in (None, ""):
+                    return str(per[i][key])
+            if pl.get(key) not in (None, ""):
+                return str(pl[key])
         return os.environ.get({"chains": "HAWQ_CHAINS", "tiles": "HAWQ_TILES", "fused_variants": "HAWQ_ER_TILES",
                                "fused_split_tiles": "HAWQ_ER_SPLIT_TILES"}[key])
 
@@ -499,7 +511,15 @@ class IntegerEngine:
         fused_split_tiles / concurrent_sub_batches): feed it back through ``IntegerEngine(model, plan=...)`` to replay it."""
         if self._batch is None:
             raise RuntimeError("export_plan: no batch shape has been built yet")
-        return {"batch": int(self._batch[0]), "chains": int(self.chains),
+
+        def strings(e):
+            return {"tiles": ".".join(str(t) for t in e.tile_choice.values()),
+                    "fused_variants": ".".join(str(t) for t in e.er_choice.values()),
+                    "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(e, "er_split_tiles", {}).values())}
+        per = [strings(e) for e in self.subs]
+        # the top-level strings are chain 0's; "per_chain" is only written when another chain runs something else
+        extra = {"per_chain": per} if any(p != per[0] for p in per[1:]) else {}
+        return {"batch": int(self._batch[0]), "chains": int(self.chains), **extra,
                 "tiles": ".".join(str(t) for t in self.tile_choice.values()),
                 "fused_variants": ".".join(str(t) for t in self.er_choice.values()),
                 "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(self, "er_split_tiles", {}).values()),
@@ -581,6 +601,7 @@ class IntegerEngine:
             for i in range(self.chains):
                 b1 = b0 + split[i]
                 sub = IntegerEngine(None, _parent=self)
+                sub._chain_index = i
                 sub._plan_on = getattr(self, "_plan_on", False)
                 sub._build(b1 - b0, H, W, self.x_in[b0:b1], self.logits[b0:b1])
                 self.subs.append(sub)
@@ -815,10 +836,6 @@ class IntegerEngine:
         n_tiles = _lib.load().hawq_conv2d_num_tiles()
         sp = self.stream.cuda_stream
         self._tile_times, self._er_times = {}, {}
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        _lib.call("hawq_event_create", C.byref(e0))
-        _lib.call("hawq_event_create", C.byref(e1))
-        ms = C.c_float()
         # replay a recorded choice, no timing: the constructor's plan for this batch size, or HAWQ_TILES (dotted list as bench.py prints it).
         # A chain of a multi-chain engine replays the plan of the WHOLE batch it is a part of
         fixed = self._fixed("tiles")
@@ -849,6 +866,11 @@ class IntegerEngine:
                     raise StalePlan("the recorded plan runs a pair as two launches but lists no tiles for them")
                 self.er_choice[name] = pair.er.tile
             return
+        # the events are created only on the timing path (the replay branch above returns or raises StalePlan without them)
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.call("hawq_event_create", C.byref(e0))
+        _lib.call("hawq_event_create", C.byref(e1))
+        ms = C.c_float()
         with torch.cuda.stream(self.stream):
             self._launch_all()  # every buffer holds valid data
             for name, a in [(n, k) for n, k in zip(self._conv_names, self._conv_args)]:

@@ -81,6 +81,11 @@ def _padded(v, n, fill=0):
     return out
 
 
+class PlanNotApplicable(NotImplementedError):
+    """The network is a configuration the fused integer plan does not take (Q_MobileNetV2.forward falls back to the module-by-module
+    path on exactly this exception; anything else - a launch error, a missing library - propagates)."""
+
+
 def _requant_bound(vmax, m, ek):
     """Upper bound on |RNE(v * m / 2^e)| for |v| <= vmax (per-channel arrays or scalars; unlifted or lifted tables alike)."""
     m = np.asarray(m, np.int64).reshape(-1)
@@ -91,6 +96,8 @@ def _requant_bound(vmax, m, ek):
 
 def _fast_scalar(s_in, s_out, vmax):
     """Scalar requant table lifted to the fast contract for inputs |v| <= vmax: (m, ek, tie) or None when it does not fit."""
+    if vmax is None:   # no bound on the producer's output is known: the exact 64-bit arithmetic runs
+        return None
     try:
         m, ek = requant_table(s_in, torch.ones(1), s_out, vbits=int(vmax).bit_length())
     except ValueError:
@@ -139,7 +146,7 @@ class _Layer:
             w9p[:, :self.cout] = w9c[:, :self.cout]
             self.w9p = torch.from_numpy(w9p).to(dev)
         else:
-            raise NotImplementedError("grouped convolutions other than depthwise 3x3 are outside MobileNetV2")
+            raise PlanNotApplicable("grouped convolutions other than depthwise 3x3 are outside MobileNetV2")
 
     def fast_closing(self, s_a, s_out, dev):
         """Fused constants (packing.pack_ctab, bias folded) of this conv's unit-closing requant when the lifted table fits the fast
@@ -230,13 +237,13 @@ class MobileNetV2Engine:
         P = self.P = {}
         qi = m.quant_input
         if qi.activation_bit != 8 or qi.quant_mode != 'symmetric':
-            raise NotImplementedError("quant_input must be 8-bit symmetric (every shipped schedule)")
+            raise PlanNotApplicable("quant_input must be 8-bit symmetric (every shipped schedule)")
         s_in = self._scale(qi)
         P['s_in'], P['inv_s_in'] = float(s_in.item()), float((1. / s_in).item())
 
         def act16(act):
             if act.activation_bit != 16 or act.quant_mode != 'symmetric':
-                raise NotImplementedError("the unit-closing QuantAct must be 16-bit symmetric (every shipped schedule)")
+                raise PlanNotApplicable("the unit-closing QuantAct must be 16-bit symmetric (every shipped schedule)")
             return self._scale(act)
 
         def activated(layer, s_a, act):
@@ -245,7 +252,7 @@ class MobileNetV2Engine:
             md, ed, mh, eh = layer.table(s_a, s_o, dev)
             lo, hi = _rng(act)
             if not _relu6_is_relu(float(s_a.item()), layer.s_w.numpy(), mh, eh, hi):
-                raise NotImplementedError("a QuantAct range above 6.0 behind ReLU6: the integer plan folds ReLU6 into the clamp")
+                raise PlanNotApplicable("a QuantAct range above 6.0 behind ReLU6: the integer plan folds ReLU6 into the clamp")
             ent = dict(m=md, e=ed, lo=max(lo, 0), hi=hi, s=s_o)
             if layer.groups == 1:
                 # the conv kernels' short requant (one v_mad_i64_i32 against a fused per-channel constant) where the lifted table
@@ -274,7 +281,7 @@ class MobileNetV2Engine:
         s16 = act16(m.quant_act_int32)
         md, ed, mh, eh = init.table(s_in, s16, dev)
         if not _relu6_is_relu(float(s_in.item()), init.s_w.numpy(), mh, eh, 32767):
-            raise NotImplementedError("quant_act_int32 range above 6.0 behind ReLU6")
+            raise PlanNotApplicable("quant_act_int32 range above 6.0 behind ReLU6")
         P['init'] = dict(layer=init, m=md, e=ed, fast=init.fast_closing(s_in, s16, dev))
         units = []
         s_prev = s16
@@ -299,12 +306,16 @@ class MobileNetV2Engine:
             md, ed, _, _ = proj.table(s_x, s_o, dev)
             d['proj'] = dict(layer=proj, m=md, e=ed, fast=proj.fast_closing(s_x, s_o, dev))
             _, _, mh3, eh3 = proj.table(s_x, s_o, dev)
-            ob = min(_requant_bound([(1 << int(v)) for v in proj.vbits], mh3, eh3), 1 << 30)
+            ob = _requant_bound([(1 << int(v)) for v in proj.vbits], mh3, eh3)
             if d['residual']:
                 m1, e1 = requant_table(s_prev, one, s_o, lift=False)
                 d['m_id'], d['e_id'] = int(m1[0]), int(e1[0])
                 d['id_fast'] = _fast_scalar(s_prev, s_o, ob_prev)
-                ob = ob + _requant_bound(ob_prev, m1, e1)   # case 1: the un-clamped sum of the two branches
+                # case 1: the un-clamped sum of the two branches.  A bound that leaves 31 bits is no bound the fast tables may be lifted
+                # for: the consumers' q_fast / id_fast stay None (they run the exact arithmetic) instead of trusting a capped figure
+                ob = None if ob_prev is None else ob + _requant_bound(ob_prev, m1, e1)
+                if ob is not None and ob > (1 << 30):
+                    ob = None
             else:
                 ob = min(ob, 32768)                          # case 0 clamps to the 16-bit range
             units.append(d)
@@ -318,17 +329,17 @@ class MobileNetV2Engine:
         s_f = act16(m.quant_act_int32_final)
         md, ed, mh, eh = fin.table(s_b, s_f, dev)
         if not _relu6_is_relu(float(s_b.item()), fin.s_w.numpy(), mh, eh, 32767):
-            raise NotImplementedError("quant_act_int32_final range above 6.0 behind ReLU6")
+            raise PlanNotApplicable("quant_act_int32_final range above 6.0 behind ReLU6")
         P['final'] = dict(layer=fin, m=md, e=ed, fast=fin.fast_closing(s_b, s_f, dev))
         ao = m.quant_act_output
         s8 = self._scale(ao)
         mq, eq = requant_table(s_f, one, s8, lift=False)
         P['out'] = dict(mq=int(mq[0]), eq=int(eq[0]), rng=_rng(ao))
         if _rng(ao)[0] < -128 or _rng(ao)[1] > 127:
-            raise NotImplementedError("quant_act_output must fit int8")
+            raise PlanNotApplicable("quant_act_output must fit int8")
         oc = m.output
         if oc.bias is not None or tuple(oc.kernel_size) != (1, 1) or oc.groups != 1:
-            raise NotImplementedError("the classifier must be a bias-free 1x1 QuantConv2d")
+            raise PlanNotApplicable("the classifier must be a bias-free 1x1 QuantConv2d")
         if self.from_buffers or getattr(oc, "use_integer_buffers", False):
             w_int, s_w = oc.weight_integer.detach().float().cpu(), oc.conv_scaling_factor.detach().float().cpu().reshape(-1)
         else:
@@ -631,7 +642,7 @@ class MobileNetV2Engine:
         x16, _, h, w = closing(fin['layer'], fin['m'], fin['e'], q, N, h, w, None, 0, 33, True, True, None, "final_block", fast=fin['fast'], carrier16=True)
         cl = fin['layer'].cout_s
         if cl != fin['layer'].cout_p:
-            raise NotImplementedError("the final block's width must be a multiple of 64 (the pool and the classifier read dense rows)")
+            raise PlanNotApplicable("the final block's width must be a multiple of 64 (the pool and the classifier read dense rows)")
         qf = alloc(N * cl, torch.int8)
         pooled = alloc(N * cl, torch.int32) if self.keep_acc else None
         o = P['out']

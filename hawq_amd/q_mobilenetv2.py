@@ -114,14 +114,16 @@ class Q_MobileNetV2(nn.Module):
 
     def forward(self, x):
         if self.fused and x.is_cuda and not self.training and self.is_frozen():
+            from .engine_mbv2 import PlanNotApplicable
             try:
                 return self.engine()(x)
-            except NotImplementedError as exc:
+            except PlanNotApplicable as exc:
                 # a configuration the fused plan does not take (other input / unit-output QuantAct widths, a classifier bias, a
                 # ReLU6 that does not fold): the module-by-module path computes it, as it did before the plan existed
                 import warnings
                 warnings.warn(f"Q_MobileNetV2: fused integer plan not applicable ({exc}); using the module-by-module path")
                 self.fused = False
+                self._engine = None   # a half-built executor is not kept
         return self.forward_modules(x)
 
     def forward_modules(self, x):

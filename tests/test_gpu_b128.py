@@ -12,9 +12,11 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 CONFIGS = [("resnet18", "uniform8"), ("resnet50", "uniform8"), ("resnet50", "uniform4"), ("resnet50", "bops_0.5")]
+# round 5: the SURVEY 8(f).3 graphs at the benchmarked batch too (fixtures by tests/golden/make_b128.py)
+CONFIGS_F3 = [("resnet101", "uniform8"), ("resnet50b", "uniform8")]
 
 
-@pytest.mark.parametrize("arch,scheme", CONFIGS)
+@pytest.mark.parametrize("arch,scheme", CONFIGS + CONFIGS_F3)
 def test_benchmarked_configuration_is_bit_exact_at_batch_128(arch, scheme):
     import bench
     from oracle import oracle
