@@ -156,7 +156,8 @@ int hawq_conv2d(const hawq_conv_args *args, void *stream);
 int hawq_conv2d_num_tiles(void);
 /* The LAST hawq_conv2d_num_band_tiles() tile ids are special-purpose kernels (fast-contract layers only; hawq_conv2d refuses them
  * for any layer they are not built for): the 3x3/stride-1/pad-1 "band" kernels of rounds 1-3, then the weight-stationary persistent
- * kernel for Cin == Cout == 64 (int8 in and out, REQUANT, NHWC output) with one / two workgroups per CU, then (ABI 5) the
+ * kernel for Cin == Cout == 64 (int8 in and out; REQUANT - or, round 5, single-branch RESIDUAL on uint16 residuals; NHWC or planar output)
+ * with one / two workgroups per CU, then (ABI 5) the
  * hawq_conv2d_num_band2_tiles() 3x3 kernels and the hawq_conv2d_num_gemm2_tiles() streaming 1x1 kernels of round 5.  All other ids
  * take any layer. */
 int hawq_conv2d_num_band_tiles(void);
@@ -164,9 +165,10 @@ int hawq_conv2d_num_band_tiles(void);
  * fast_tables), 0 if none does: lets a caller decide whether the producer should write planar activations. */
 int hawq_conv2d_band_tile(const hawq_conv_args *args);
 /* ABI 5: hawq_conv2d_num_band2_tiles() of those ids (the ones in front of the 1x1 kernels) are the round-5 3x3 kernels (band_v2.hip; need args->wgt_band and
- * in_planar == 1; int8 operands, Cin >= 128; REQUANT, or single-branch RESIDUAL on uint16 residuals; int8 NHWC or planar output).  hawq_conv2d_band2_tile: 1-based id of the first of them that takes the layer as described, else 0.
+ * in_planar == 1; int8 operands with Cin >= 128, or hawq4 operands (in_bits == w_bits == 4) with Cin >= 256; REQUANT, or single-branch RESIDUAL on uint16
+ * residuals; int8 / hawq4 output, NHWC or planar).  hawq_conv2d_band2_tile: 1-based id of the first of them that takes the layer as described, else 0.
  * hawq_pack_w3x3_band: [Cout][3][3][Cin] int8 (the layout of `wgt`) -> the stream described at hawq_conv_args.wgt_band, on the host
- * (dst and src are host pointers of Cout * 9 * Cin bytes; Cin and Cout multiples of 64). */
+ * (dst and src are host pointers of Cout * 9 * Cin bytes; Cin = BYTES per tap row - the channel count for int8 weights, half of it for hawq4 -; Cin and Cout multiples of 64). */
 int hawq_conv2d_num_band2_tiles(void);
 int hawq_conv2d_band2_tile(const hawq_conv_args *args);
 int hawq_pack_w3x3_band(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin);
