@@ -107,6 +107,9 @@ def spin_up(eng, seconds=0.7):
     REPLAYING a recorded plan reaches the timed region after a few milliseconds of GPU work, and the first ~100 ms after idle run at ramping
     clocks (measured: 87.7 k img/s for a replayed plan straight after the build vs 93-94 k for the same plan after a tuned run's launches;
     the driver's --warmup 5 is 7 ms).  Applied to tuned and replayed engines alike."""
+    # HAWQ_BENCH_SPIN_UP=<seconds> (tools/profile_round.sh sets 0 for its counter passes: the totals of two runs are subtracted, so
+    # both must launch the same number of forwards, which a time-based loop under a profiler does not)
+    seconds = float(os.environ.get("HAWQ_BENCH_SPIN_UP", seconds))
     t0 = time.perf_counter()
     with torch.cuda.stream(eng.stream):
         while time.perf_counter() - t0 < seconds:

@@ -28,10 +28,12 @@ fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $R/bench.py $W $P --no-cpu-baseline --no-extra --steps 20 --warmup 5 > $O/${tag}_bench_under_rocprof.json 2>/dev/null
 python $R/tools/rocprof_summary.py $(find /tmp/kt -name "*.db" | head -1) > $O/${tag}_kernel_trace.md
+CHN=$(python -c "import json; print(json.loads(open('$O/${tag}_bench.json').readline())['config']['concurrent_sub_batches'])")
+python $R/tools/rocprof_overlap.py $(find /tmp/kt -name "*.db" | head -1) 10 $CHN > $O/${tag}_kernel_overlap.md 2>&1
 rm -f $O/${tag}_pmc_totals.txt
 for ctr in FETCH_SIZE WRITE_SIZE; do
   for steps in 2 12; do
-    rm -rf /tmp/pm; rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm -o r -- python $R/bench.py $W $P --no-cpu-baseline --no-extra --steps $steps --warmup 1 > /dev/null 2>&1
+    rm -rf /tmp/pm; HAWQ_BENCH_SPIN_UP=0 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm -o r -- python $R/bench.py $W $P --no-cpu-baseline --no-extra --steps $steps --warmup 1 > /dev/null 2>&1
     echo "$ctr steps=$steps $(python $R/tools/pmc_total.py $(find /tmp/pm -name '*.db' | head -1))" >> $O/${tag}_pmc_totals.txt
     if [ $steps = 12 ] && [ -z "$LIGHT" ]; then python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) 20 > $O/${tag}_pmc_${ctr}.md; fi
   done
@@ -67,3 +69,14 @@ json.dump(out, open("$O/${tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 cat $O/${tag}_pmc_totals.txt
+# the four passes must have launched the same number of kernels apart from the 10 extra forwards (else the subtraction is void)
+python - <<PY
+import re
+n = {}
+for line in open("$O/${tag}_pmc_totals.txt"):
+    m = re.match(r"(\w+) steps=(\d+) \1 ([\d.e+]+) (\d+)", line)
+    if m:
+        n[(m[1], int(m[2]))] = int(m[4])
+ok = n[("FETCH_SIZE", 2)] == n[("WRITE_SIZE", 2)] and n[("FETCH_SIZE", 12)] == n[("WRITE_SIZE", 12)]
+print("dispatch counts of the counter passes", "agree" if ok else "DIFFER - traffic figure invalid", n)
+PY
