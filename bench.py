@@ -615,6 +615,8 @@ def main():
                          # measured counterpart; floor = those bytes at the measured copy ceiling of the part
                          "fused_plan_bytes_per_launch": plan_bytes,
                          "plan_floor_ms": round(floor_ms, 4), "plan_floor_ratio": round(gpu_ms / floor_ms, 3),
+                         # counter traffic over the bytes the plan has to move (> 1: re-reads / Infinity-Cache-side requests beyond the model)
+                         "traffic_over_plan_bytes": round(traffic / plan_bytes, 3) if traffic and plan_bytes else None,
                          "mfma_frac": round(mfma_frac, 4)},
         }
         out["roofline"]["dominant_kernel"] = dominant_kernel(eng, args, plan_rows(args.arch, args.scheme) if args.arch in roofline.ARCH else {})

@@ -44,9 +44,9 @@ if [ -z "$LIGHT" ]; then
   python $R/tools/pmc_summary.py $(find /tmp/pm -name "*.db" | head -1) 8 > $O/${tag}_pmc_MFMA.md
   python $R/tools/pmc_total.py $(find /tmp/pm -name "*.db" | head -1) > $O/${tag}_pmc_MFMA_totals.txt
   python $R/tools/mfma_util.py $O/${tag}_pmc_MFMA.md > $O/${tag}_mfma_utilisation.md
-  CH=$(python -c "import json; print(json.loads(open('$O/${tag}_bench.json').readline())['config']['concurrent_sub_batches'])")
-  python $R/tools/dominant_kernel.py $(find /tmp/kt -name "*.db" | head -1) $O/${tag}_pmc_MFMA.md ${ARCH}_${SCHEME}_b128 ${GRAFT_HEAD:-unknown} $CH > $O/${tag}_dominant_kernel.json
 fi
+# the dominant kernel of the forward (bench.py: roofline.dominant_kernel) from the kernel trace above; LIGHT runs have no MFMA pass (mfma_busy_frac null)
+python $R/tools/dominant_kernel.py $(find /tmp/kt -name "*.db" | head -1) $O/${tag}_pmc_MFMA.md ${ARCH}_${SCHEME}_b128 ${GRAFT_HEAD:-unknown} $CHN > $O/${tag}_dominant_kernel.json
 python - <<PY
 import json, re
 tot = {}
