@@ -66,6 +66,8 @@ SIGNATURES = {
     "hawq_conv2d_num_gemm2_tiles": [],
     "hawq_conv2d_gemm2_first": [],
     "hawq_pack_w1x1_k128": [vp, vp, i32, i32],
+    "hawq_fc_dequant_ok": [i32, i32, i32],
+    "hawq_fc_dequant": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "hawq_conv_expand_reduce": [C.POINTER(ExpandReduceArgs), vp],
     "hawq_conv_expand_reduce_variants": [C.POINTER(ExpandReduceArgs)],
     "hawq_linear_bottleneck": [C.POINTER(BottleneckArgs), vp],

@@ -446,7 +446,7 @@ class IntegerEngine:
                 self.chains = max(1, int(self.plan["chains"]))
                 self._build_chains(N, H, W, x_view, logits_view)
                 names = self.plan.get("conv_launches")
-                if names is not None and list(names) != list(self.tile_choice.keys()):
+                if names is not None and any(n not in names for n in self.tile_choice.keys()):
                     raise StalePlan("recorded for another launch list (other network, schedule or storage rule)")
                 self.plan_source = self.plan.get("source", "replayed a recorded plan")
                 return
@@ -811,9 +811,15 @@ class IntegerEngine:
         if self.keep_acc:
             self._add_acc_tap(ops, keep, a, 'quant_output', N, 1, 1, fc['nout_p'])
         ops.next_name = "quant_output"
-        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
-        self._conv_args.append(a)  # the FC GEMM (M = batch, K = 2048) is tile-tuned like the convs
-        self._conv_names.append("quant_output")
+        if _lib.load().hawq_fc_dequant_ok(N, fc['k'], fc['nout_p']) and not os.environ.get("HAWQ_NO_FC2"):
+            # round 5: the classifier's own kernel (fc_dequant.hip; K split over the waves of a workgroup, no LDS staging) - the same bytes as the
+            # DEQUANT epilogue of hawq_conv2d, nothing to tune
+            ops.append(partial(_lib.call, "hawq_fc_dequant", qf.data_ptr(), fc['w'].data_ptr(), fc['bias'].data_ptr(), fc['fscale'].data_ptr(),
+                               self.logits.data_ptr(), N, fc['k'], fc['nout_p'], fc['nout'], fc['nout'], sp))
+        else:
+            ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+            self._conv_args.append(a)  # the FC GEMM (M = batch, K = 2048) is tile-tuned like the convs
+            self._conv_names.append("quant_output")
         keep += [qf, pooled, a]
         self._ops, self._keep, self._batch = ops, keep, (N, H, W)
         self._graph = None
@@ -855,6 +861,13 @@ class IntegerEngine:
         fixed = self._fixed("tiles")
         if fixed:
             ids = [int(v) for v in fixed.split(".")]
+            names = (self.plan or {}).get("conv_launches") if getattr(self, "_plan_on", False) else None
+            if names is not None and len(names) == len(ids) and list(names) != list(self._conv_names):
+                # a plan recorded with launches this build no longer tunes (the classifier since round 5): replay by NAME, ignore the extra ones
+                by_name = dict(zip(names, ids))
+                if any(n not in by_name for n in self._conv_names):
+                    raise StalePlan("recorded for another launch list (other network, schedule or storage rule)")
+                ids = [by_name[n] for n in self._conv_names]
             if len(ids) != len(self._conv_args):
                 raise StalePlan(f"the recorded plan lists {len(ids)} tiles, this plan has {len(self._conv_args)} conv launches")
             counts = self.plan.get("pair_variant_counts") if getattr(self, "_plan_on", False) else None

@@ -660,8 +660,13 @@ class MobileNetV2Engine:
         a.out_f32, a.fscale, a.ldo, a.n_valid = self.logits.data_ptr(), fc['fscale'].data_ptr(), fc['nout'], fc['nout']
         if self.keep_acc:
             self._tap(ops, keep, "output", a, N, 1, 1, fc['nout'], fc['nout_p'])
-        self._convs.append(("output", a))
-        ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
+        if _lib.load().hawq_fc_dequant_ok(N, fc['k'], fc['nout_p']) and not os.environ.get("HAWQ_NO_FC2"):
+            # round 5: the classifier's own kernel (fc_dequant.hip), the same bytes as the DEQUANT epilogue; nothing to tune
+            ops.append(partial(_lib.call, "hawq_fc_dequant", qf.data_ptr(), fc['w'].data_ptr(), fc['bias'].data_ptr(), fc['fscale'].data_ptr(),
+                               self.logits.data_ptr(), N, fc['k'], fc['nout_p'], fc['nout'], fc['nout'], sp))
+        else:
+            self._convs.append(("output", a))
+            ops.append(partial(_lib.call, "hawq_conv2d", C.byref(a), sp))
         keep += [qf, pooled, a]
         self._ops, self._keep, self._batch = ops, keep, (N, H, W)
 

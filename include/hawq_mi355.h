@@ -258,6 +258,16 @@ int hawq_avgpool_requant(const void *in, int32_t in_bits, int32_t N, int32_t HW,
                          int32_t *pooled_out, int32_t mq, int32_t eq, int32_t q_lo, int32_t q_hi,
                          void *stream);
 
+/* QuantLinear on the frozen integer path (quant_modules.py:112-130: F.linear(x_int, weight_integer, bias_integer) * (fc_scaling_factor *
+ * prev_act_scaling_factor); the classifier of every Q_ResNet, q_resnet.py:132-134) as its own launch (fc_dequant.hip, round 5):
+ *   out_f32[n * ldo + o] = (float)(sum_k q[n][k] * wgt[o][k] + bias[o]) * fscale[o]      for o < n_valid
+ * q [N][K] int8, wgt [Nout_p][K] int8 (row-major = the [Cout][1][1][Cin] layout hawq_conv2d takes), bias / fscale [Nout_p].  The same bytes
+ * as hawq_conv2d with epilogue DEQUANT on the 1 x 1 map (tests/test_gpu_kernels.py), several times faster for the M = batch, long-K
+ * shape.  hawq_fc_dequant_ok: K % 128 == 0 and Nout_p % 32 == 0. */
+int hawq_fc_dequant_ok(int32_t N, int32_t K, int32_t Nout_p);
+int hawq_fc_dequant(const int8_t *q, const int8_t *wgt, const int32_t *bias, const float *fscale, float *out_f32, int32_t N, int32_t K,
+                    int32_t Nout_p, int32_t n_valid, int32_t ldo, void *stream);
+
 /* ---- module-compatible (fp32 tuple convention) adapters ---------------------------------
  * The reference modules exchange fp32 tensors holding integer*scale.  These kernels move
  * between that convention (NCHW fp32) and the integer NHWC tensors the conv kernels use. */

@@ -550,6 +550,39 @@ def test_dequant_epilogue_fc(lib, orc):
 
 
 # ---------------------------------------------------------------- fp32-convention adapters vs live-reference KATs
+@pytest.mark.parametrize("n,k,nout", [(1, 512, 10), (37, 2048, 1000), (64, 2048, 1000), (128, 512, 1000), (64, 1280, 1000), (33, 128, 33)])
+def test_fc_dequant_kernel_equals_the_conv_kernels_dequant_epilogue(lib, orc, n, k, nout):
+    """QuantLinear's frozen path (quant_modules.py:112-130) through its own kernel (fc_dequant.hip, round 5): the int32 sums are the
+    CPU oracle's, the fp32 logits are bit for bit numpy's float32 product and those of hawq_conv2d's DEQUANT epilogue."""
+    from hawq_amd.packing import pack_conv_weight
+    rng = np.random.default_rng(n * 7 + k)
+    x = rng.integers(-128, 128, (n, k)).astype(np.int64)
+    wt = rng.integers(-127, 128, (nout, k)).astype(np.int64)
+    b = rng.integers(-3000, 3000, nout).astype(np.int64)
+    nout_p = (nout + 63) // 64 * 64
+    fsp = np.zeros(nout_p, f32)
+    fsp[:nout] = rng.uniform(1e-5, 1e-3, nout).astype(f32)
+    bp = np.zeros(nout_p, np.int32)
+    bp[:nout] = b
+    wp = dev(pack_conv_weight(wt.reshape(nout, k, 1, 1), 8, k, nout_p))
+    xd, bd, fd = dev(x.astype(np.int8)), dev(bp), dev(fsp)
+    assert lib.load().hawq_fc_dequant_ok(n, k, nout_p)
+    out = torch.full((n, nout), -7.0, dtype=torch.float32, device="cuda")
+    lib.call("hawq_fc_dequant", xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), fd.data_ptr(), out.data_ptr(), n, k, nout_p, nout, nout, stream())
+    torch.cuda.synchronize()
+    ref = (orc.linear(x, wt, b).astype(f32) * fsp[:nout].reshape(1, -1)).astype(f32)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    a = lib.ConvArgs()
+    a.in_, a.wgt, a.bias = xd.data_ptr(), wp.data_ptr(), bd.data_ptr()
+    a.N, a.H, a.W, a.Cin, a.Cout, a.KH, a.KW, a.stride, a.pad = n, 1, 1, k, nout_p, 1, 1, 1, 0
+    a.in_bits, a.w_bits, a.epilogue = 8, 8, lib.EPI_DEQUANT
+    via_conv = torch.full((n, nout), -9.0, dtype=torch.float32, device="cuda")
+    a.out_f32, a.fscale, a.ldo, a.n_valid = via_conv.data_ptr(), fd.data_ptr(), nout, nout
+    lib.call("hawq_conv2d", C.byref(a), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, via_conv)
+
+
 def test_fixedpoint_fn_matches_reference_kats():
     from hawq_amd.quant_utils import fixedpoint_fn
     kf = H.load("kat_functions.npz")
