@@ -326,8 +326,24 @@ def dominant_kernel(eng, args, rows):
     ids = next((r for k, r in fam.items() if k in rec["rocprof_name"]), None)
     fused = {p.split("+")[0] for p in getattr(eng, "er_choice", {}) if eng.er_choice[p]}
     chains = max(1, getattr(eng, "chains", 1))
-    if ids is not None and rows:
+    names = None
+    if ids is not None:
         names = [k for k, t in eng.tile_choice.items() if t in ids and k.split("+")[0] not in fused]
+    elif "expand_" in rec["rocprof_name"]:
+        # a fused expand (-> reduce) kernel: the pairs that share the variant id which as many pairs run as the trace saw launches per chain
+        import re as _re
+        per_chain = round(rec["launches_per_forward"] / chains)
+        by_variant = {}
+        for k, v in getattr(eng, "er_choice", {}).items():
+            if v:
+                by_variant.setdefault(v, []).append(k)
+        cands = [ks for ks in by_variant.values() if len(ks) == per_chain]
+        if len(cands) == 1:
+            names = []
+            for k in cands[0]:
+                m = _re.match(r"(stage\d+)\.unit(\d+)\.quant_convbn3$", k)
+                names.append(f"{k}+{m[1]}.unit{int(m[2]) + 1}.quant_convbn1" if m else k.split("@")[0])
+    if names and rows:
         byt = sum(launch_model(k, rows, args.batch // chains)[0] for k in names)
         mac = sum(launch_model(k, rows, args.batch // chains)[1] for k in names)
         t = len(names) * rec["avg_us"] * 1e-6
@@ -619,7 +635,10 @@ def main():
                          "traffic_over_plan_bytes": round(traffic / plan_bytes, 3) if traffic and plan_bytes else None,
                          "mfma_frac": round(mfma_frac, 4)},
         }
-        out["roofline"]["dominant_kernel"] = dominant_kernel(eng, args, plan_rows(args.arch, args.scheme) if args.arch in roofline.ARCH else {})
+        try:
+            out["roofline"]["dominant_kernel"] = dominant_kernel(eng, args, plan_rows(args.arch, args.scheme) if args.arch in roofline.ARCH else {})
+        except Exception as exc:   # a reporting extra must never cost the bench line
+            out["roofline"]["dominant_kernel"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world > 1:
             out["weak"], out["strong"] = runs["weak"], runs.get("strong")
         if (not args.no_extra or args.per_op) and world == 1:
