@@ -560,3 +560,87 @@ def test_pack_w3x3_band_matches_the_c_twin_and_a_loop_restatement():
         assert np.array_equal(dst, ref)
     bad = np.zeros(16, np.uint8)
     assert lib.hawq_pack_w3x3_band(bad.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), 32, 64) != 0
+
+
+def test_pack_w1x1_k128_matches_the_c_twin_and_a_loop_restatement():
+    """ABI 5: the weight stream of the round-5 streaming 1x1 kernels (include/hawq_mi355.h: hawq_conv_args.wgt_k128): [Cout/64][Cin/128]
+    [64 rows][128 B], 16-byte slot s of row r at s ^ ((r >> 1) & 7).  numpy packer, C twin (host pointers, no GPU) and a loop
+    restatement of the documented layout agree byte for byte; sizes the kernels do not take are refused."""
+    import ctypes
+    from hawq_amd import _lib
+    from hawq_amd.packing import pack_w1x1_k128
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    for cout, cin in ((64, 128), (128, 384), (192, 256)):
+        w = rng.integers(-128, 128, (cout, cin)).astype(np.int8).view(np.uint8)
+        got = pack_w1x1_k128(w.reshape(-1), cout, cin)
+        ref = np.zeros(cout * cin, np.uint8)
+        kch = cin // 128
+        for ct in range(cout // 64):
+            for kc in range(kch):
+                base = (ct * kch + kc) * 64 * 128
+                for r in range(64):
+                    row = w[ct * 64 + r, kc * 128:kc * 128 + 128]
+                    for sl in range(8):
+                        o = base + r * 128 + ((sl ^ ((r >> 1) & 7)) << 4)
+                        ref[o:o + 16] = row[sl * 16:sl * 16 + 16]
+        assert np.array_equal(got, ref)
+        dst = np.zeros_like(ref)
+        src = np.ascontiguousarray(w.reshape(-1))
+        assert lib.hawq_pack_w1x1_k128(src.ctypes.data_as(ctypes.c_void_p), dst.ctypes.data_as(ctypes.c_void_p), cout, cin) == 0
+        assert np.array_equal(dst, ref)
+    bad = np.zeros(64, np.uint8)
+    assert lib.hawq_pack_w1x1_k128(bad.ctypes.data_as(ctypes.c_void_p), bad.ctypes.data_as(ctypes.c_void_p), 64, 64) != 0
+
+
+def test_recorded_plan_is_replayed_per_chain_and_by_launch_name():
+    """ADVICE r4 / round 5, host logic only (no GPU): a chain of a multi-chain engine reads ITS entry of a plan's `per_chain` list, the
+    top-level strings otherwise; a chain the plan does not list makes the plan stale; `chains` is never read per chain."""
+    from hawq_amd.engine import IntegerEngine, StalePlan
+    e = IntegerEngine.__new__(IntegerEngine)
+    e.plan = {"chains": 2, "tiles": "1.2.3", "fused_variants": "1.0", "per_chain": [{"tiles": "1.2.3", "fused_variants": "1.0"},
+                                                                                   {"tiles": "4.5.6", "fused_variants": ""}]}
+    e._plan_on = True
+    assert e._fixed("tiles") == "1.2.3" and e._fixed("chains") == "2"          # the parent engine: top-level strings
+    e._chain_index = 1
+    assert e._fixed("tiles") == "4.5.6"
+    assert e._fixed("fused_variants") == "1.0"                                  # an empty per-chain entry falls back to the top level
+    assert e._fixed("chains") == "2"
+    e._chain_index = 2
+    with pytest.raises(StalePlan):
+        e._fixed("tiles")
+    e._plan_on = False                                                          # plan not applicable to this batch shape: environment or tune
+    os.environ.pop("HAWQ_TILES", None)
+    assert e._fixed("tiles") is None
+
+
+def test_profile_tools_on_a_synthetic_kernel_trace(tmp_path):
+    """tools/dominant_kernel.py and tools/rocprof_overlap.py (run on the GPU box by tools/profile_round.sh) against a hand-made
+    rocprofv3-style `kernels` table: two chains, three forwards, stem + two convs per chain and forward, one tuning kernel."""
+    import json
+    import sqlite3
+    import subprocess
+    import sys
+    db = tmp_path / "r.db"
+    c = sqlite3.connect(db)
+    c.execute("create table kernels (name text, start integer, end integer, duration integer, vgpr_count integer, accum_vgpr_count integer, lds_size integer)")
+    t = 0
+    rows = [("minmax_kernel", 0, 5000, 5000, 20, 0, 0)]
+    for f in range(3):
+        for ch in range(2):
+            s0 = 10_000 + f * 100_000 + ch * 2_000          # the second chain starts 2 us after the first: the kernels overlap
+            rows.append(("void stem_fused_kernel<false>(P)", s0, s0 + 10_000, 10_000, 48, 0, 26016))
+            rows.append(("void conv3x3_v2_kernel<V2Cfg<2, 2, 2, 4, 256, 3>, 1, 0, false>(B2P)", s0 + 11_000, s0 + 31_000, 20_000, 72, 0, 81920))
+            rows.append(("void conv_kernel<Cfg<64, 64, 2, 2, 2, 1, 6, 1>, 1, false, 136, 0, false>(ConvP)", s0 + 32_000, s0 + 37_000, 5_000, 32, 0, 25600))
+    c.executemany("insert into kernels values (?,?,?,?,?,?,?)", rows)
+    c.commit()
+    c.close()
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dominant_kernel.py"), str(db), str(tmp_path / "no_pmc.md"), "w", "abc1234", "2"],
+                         capture_output=True, text=True, check=True).stdout
+    rec = json.loads(out)["w"]
+    assert rec["rocprof_name"].startswith("void conv3x3_v2_kernel<V2Cfg<2, 2, 2, 4, 256, 3>")
+    assert rec["launches_per_forward"] == 2.0 and rec["avg_us"] == 20.0 and rec["mfma_busy_frac"] is None and rec["git_head"] == "abc1234"
+    assert abs(rec["share_of_forward_kernel_time"] - 20 / 35) < 1e-3 and rec["forward_kernels_in_trace"] == 3      # the tuning kernel is not counted
+    ov = subprocess.run([sys.executable, os.path.join(root, "tools", "rocprof_overlap.py"), str(db), "2", "2"], capture_output=True, text=True, check=True).stdout
+    assert "last 2 forwards (2 chains): 12 kernels" in ov and "| 2 |" in ov and "| 0 |" in ov
