@@ -16,11 +16,13 @@ n_g2 = L.hawq_conv2d_num_gemm2_tiles()
 n_all, n_b1, n_b2 = L.hawq_conv2d_num_tiles() - n_g2, L.hawq_conv2d_num_band_tiles() - n_g2, L.hawq_conv2d_num_band2_tiles()
 first_band = n_all - n_b1
 planar_out = int(os.environ.get("PLANAR_OUT", "0"))
-shapes = [(56, 64), (28, 128), (14, 256), (7, 512)]
+shapes = [(56, 64, 64), (28, 128, 128), (14, 256, 256), (7, 512, 512)]
 shapes = [shapes[int(i)] for i in os.environ.get("SHAPES", "0,1,2,3").split(",")]
+# SWEEP_CIN="128,256,512,1024": slope / intercept probe - the selected maps with Cout fixed and Cin (= the number of K steps, 3 per 64 channels) swept
+if os.environ.get("SWEEP_CIN"):
+    shapes = [(h, int(c), cout) for (h, _, cout) in shapes for c in os.environ["SWEEP_CIN"].split(",")]
 for n in batches:
-    for (h, cin) in shapes:
-        cout = cin
+    for (h, cin, cout) in shapes:
         M = n * h * h
         x = rng.integers(0, 128, (M, cin)).astype(np.int8)
         xp = torch.from_numpy(np.ascontiguousarray(x.reshape(M, cin // 16, 16).transpose(1, 0, 2))).cuda()
@@ -66,5 +68,5 @@ for n in batches:
             gmac = M * cout * cin * 9 / 1e9
             same = bool(torch.equal(got, ref))
             nbad = 0 if same else int((got != ref).sum())
-            print(f"B={n} {h}x{h} C={cin} {'v2  ' if is_v2 else 'band'} tile {bt - first_band}: {us:7.1f} us  {gmac / us / 2.2 * 100:5.1f} % of 2.2 PMAC/s  same={same}"
+            print(f"B={n} {h}x{h} C={cin}{'' if cin == cout else '->' + str(cout)} {'v2  ' if is_v2 else 'band'} tile {bt - first_band}: {us:7.1f} us  {gmac / us / 2.2 * 100:5.1f} % of 2.2 PMAC/s  same={same}"
                   + ("" if same else f" ({nbad} of {got.numel()} bytes differ)"), flush=True)
