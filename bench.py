@@ -432,7 +432,9 @@ def dry_main(args, rank, world):
     if world_seen != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the process group has {world_seen} ranks")
     # every rank "tunes" something else (as independent tuning passes do); after share_plan all hold rank 0's plan
-    own = {"batch": args.batch, "chains": 2, "tiles": ".".join(str(3 + rank + i) for i in range(5)), "fused_variants": f"{1 + rank}.0"}
+    own = {"batch": args.batch, "chains": 2, "tiles": ".".join(str(3 + rank + i) for i in range(5)), "fused_variants": f"{1 + rank}.0",
+           # chains whose choices differ are recorded one by one (IntegerEngine.export_plan): a nested list must travel too
+           "per_chain": [{"tiles": ".".join(str(3 + rank + i) for i in range(5))}, {"tiles": ".".join(str(4 + rank + i) for i in range(5))}]}
     plan = share_plan(own)
     same_plan = plans_identical(plan)
     w = torch.randn(3 * 8 * 8, 10, generator=torch.Generator().manual_seed(0))
