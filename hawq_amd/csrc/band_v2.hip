@@ -41,6 +41,8 @@ struct B2P {
     const char *in;        // planes [Cin/16][M][16 B] int8
     const char *wgt;       // hawq_pack_w3x3_band stream
     const int32_t *ctab;   // [Cout][4]
+    const int32_t *bias;   // RAW only
+    int32_t *out_acc;      // RAW only: [M][Cout] int32 (accumulators + bias)
     char *out;             // NHWC [M][Cout] int8, or planes [Cout/16][M][16 B]
     const char *res_in;    // RESIDUAL: [M][Cout] uint16
     char *res_out;         // RESIDUAL: [M][Cout] uint16 or null
@@ -137,7 +139,8 @@ __device__ __forceinline__ void b2_store_q(const B2P &p, const int (&w)[4], int 
     }
 }
 
-// EPI: HAWQ_EPI_REQUANT, or HAWQ_EPI_RESIDUAL (single branch, uint16 residuals: the second conv of a basic block).
+// EPI: HAWQ_EPI_REQUANT, HAWQ_EPI_RESIDUAL (single branch, uint16 residuals: the second conv of a basic block), or HAWQ_EPI_RAW (round 6:
+// the int32 accumulators + bias as a dense [M][Cout] tensor - what the parity tests compare with the oracle's exact sums).
 // MODE: 0 = tie-free tables, 2 = exact-tie correction on every requant (fast_tables bit 2).
 // NIB: both operands hawq4.
 template <class C, int EPI, int MODE, bool NIB>
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
         const int dw = wave - C::NW;
         const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)p.in_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)p.wgt, 0, (int)p.wgt_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rct = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctab, 0, p.Cout * 16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rct = __builtin_amdgcn_make_buffer_rsrc((void *)p.ctab, 0, EPI == HAWQ_EPI_RAW ? 0 : p.Cout * 16, 0x00020000);   // (RAW: no constants - zero records, the DMA writes zeros)
         unsigned bvo[C::PG];   // byte offset of this lane's pixel inside a plane, or out of range (the hardware then writes zeros)
 #pragma unroll
         for (int g = 0; g < C::PG; ++g) {
@@ -419,6 +422,23 @@ __global__ __launch_bounds__(C::NT, C::MINW) void conv3x3_v2_kernel(const B2P p)
     if (g == 0) exchange(std::integral_constant<int, 0>{}); else exchange(std::integral_constant<int, 1>{});
     const long long t_xch = prof ? (long long)__builtin_readcyclecounter() : 0;
     // ---------------------------------------------------------------------- requantisation + stores (no staging tile)
+    if constexpr (EPI == HAWQ_EPI_RAW) {   // a lane's 16 consecutive channels of one pixel: 64 contiguous bytes
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = c0 + c * 32 + h * 16;
+#pragma unroll
+            for (int qq = 0; qq < C::HQ; ++qq) {
+                const int m = m0 + wave_m * (32 * C::PT) + (g * C::HQ + qq) * 32 + l31;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const v4i b4 = *reinterpret_cast<const v4i *>(p.bias + ch + 4 * gq);
+                    const v4i v = {sum[c][qq][4 * gq] + b4.x, sum[c][qq][4 * gq + 1] + b4.y, sum[c][qq][4 * gq + 2] + b4.z, sum[c][qq][4 * gq + 3] + b4.w};
+                    reinterpret_cast<v4i *>(p.out_acc + (size_t)m * p.Cout + ch)[gq] = v;
+                }
+            }
+        }
+    }
     if constexpr (EPI == HAWQ_EPI_REQUANT) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -517,10 +537,11 @@ using V256 = V2Cfg<2, 4, 4, 5, 384, 3>;    // 256 px x 64 ch: 8 MFMA waves + 4 p
 constexpr int NUM_V2 = 2;
 
 typedef void (*V2Fn)(const B2P);
-struct V2Info { V2Fn fn[2][2][2]; int bm, band_px, lds, nt, tight; };   // fn[hawq4][residual][exact-tie]
+struct V2Info { V2Fn fn[2][2][2]; V2Fn raw[2]; int bm, band_px, lds, nt, tight; };   // fn[hawq4][residual][exact-tie]; raw[hawq4]
 #define V2_FNS(CFG, N) {{conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 0, N>, conv3x3_v2_kernel<CFG, HAWQ_EPI_REQUANT, 2, N>}, \
                         {conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 0, N>, conv3x3_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, 2, N>}}
-#define V2_ENTRY(CFG) {{V2_FNS(CFG, false), V2_FNS(CFG, true)}, CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
+#define V2_ENTRY(CFG) {{V2_FNS(CFG, false), V2_FNS(CFG, true)}, {conv3x3_v2_kernel<CFG, HAWQ_EPI_RAW, 0, false>, conv3x3_v2_kernel<CFG, HAWQ_EPI_RAW, 0, true>}, \
+                       CFG::BM, CFG::BAND_PX, CFG::LDS_BYTES, CFG::NT, CFG::TIGHT}
 const V2Info kV2[NUM_V2] = {V2_ENTRY(V128), V2_ENTRY(V256)};
 
 }  // namespace
@@ -550,14 +571,16 @@ bool band_v2_applies(const hawq_conv_args *a, int v) {
     const long long M = (long long)a->N * a->H * a->W;
     const int band_len = vi.bm + 2 * a->W + 2 + 7;   // pixels m0 - Wo - 1 .. m0 + BM + Wo, start rounded down to a line
     const bool qout_ok = a->out_bits == 8 || (a->out_bits == 4 && a->q_lo >= 0 && a->q_hi <= 15 && a->Cout % 32 == 0);
-    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && qout_ok && (a->out_bits == 8 || a->relu || a->q_lo >= 0)) ||
+    const bool raw = a->epilogue == HAWQ_EPI_RAW;
+    const bool epi_ok = (raw && a->out_acc && a->bias) ||
+                        (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && qout_ok && (a->out_bits == 8 || a->relu || a->q_lo >= 0)) ||
                         (a->epilogue == HAWQ_EPI_RESIDUAL && a->res_in && a->res_in_bits == 16 && (!a->res_out || (a->res_out_bits == 16 && a->flags)) &&
                          !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || qout_ok));
     const bool nib = a->in_bits == 4 && a->w_bits == 4;
     const int rowb = nib ? a->Cin >> 1 : a->Cin;   // bytes per pixel
-    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && a->fast_tables != 0 && a->wgt_band != nullptr &&
+    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in2 == nullptr && (raw || (a->fast_tables != 0 && a->ctab)) && a->wgt_band != nullptr &&
            a->in_planar == 1 && epi_ok && ((a->in_bits == 8 && a->w_bits == 8) || (nib && a->Cin % 128 == 0)) &&
-           a->ctab && (a->in_pitch == 0 || a->in_pitch == rowb) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
+           (a->in_pitch == 0 || a->in_pitch == rowb) && (a->out_pitch == 0 || a->out_pitch == a->Cout) &&
            band_len <= vi.band_px - 4 && rowb / 64 * 3 >= 6 && M * rowb < (1ll << 31) && (long long)a->Cout * rowb * 9 < (1ll << 31);
 }
 
@@ -565,6 +588,7 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     const V2Info &vi = kV2[v];
     B2P p;
     p.in = (const char *)a->in, p.wgt = (const char *)a->wgt_band, p.ctab = a->ctab, p.out = (char *)a->out_q;
+    p.bias = a->bias, p.out_acc = a->out_acc;
     p.res_in = (const char *)a->res_in, p.res_out = (char *)a->res_out, p.flags = a->flags;
     p.M = a->N * a->H * a->W, p.Ho = a->H, p.Wo = a->W, p.Cin = a->Cin, p.Cout = a->Cout;
     const bool nib = a->in_bits == 4;
@@ -582,12 +606,16 @@ int band_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void 
     static const bool attrs = [] {
         bool good = true;
         for (const V2Info &i : kV2)
+        {
             for (int k = 0; k < 8; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k >> 2][(k >> 1) & 1][k & 1], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+            for (int k = 0; k < 2; ++k) good &= hipFuncSetAttribute((const void *)i.raw[k], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+        }
         return good;
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv2d: hipFuncSetAttribute failed for the round-5 3x3 kernels");
     const int grid = ((p.M + vi.bm - 1) / vi.bm) * (p.Cout >> 6);
-    hipLaunchKernelGGL(vi.fn[nib ? 1 : 0][a->epilogue == HAWQ_EPI_RESIDUAL ? 1 : 0][exact_tie ? 1 : 0], dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
+    V2Fn fn = a->epilogue == HAWQ_EPI_RAW ? vi.raw[nib ? 1 : 0] : vi.fn[nib ? 1 : 0][a->epilogue == HAWQ_EPI_RESIDUAL ? 1 : 0][exact_tie ? 1 : 0];
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(vi.nt), vi.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {   // experiment hook (synchronises!)
         long long hb[6];

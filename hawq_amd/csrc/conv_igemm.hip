@@ -1619,6 +1619,8 @@ extern "C" int hawq_conv2d(const hawq_conv_args *a, void *stream) {
         tile = -1;
         for (int k = 0; k < NUM_BAND_TILES && tile < 0; ++k)
             if (band_applies(kBand[kBandPreference[k]], a)) tile = NUM_TILES + kBandPreference[k];
+        for (int v = 0; v < band_v2_count() && tile < 0; ++v)   // a layer only the round-5 kernels take
+            if (band_v2_applies(a, v)) tile = NUM_TILES + NUM_BAND_TILES + 2 + v;
         HAWQ_REQUIRE(tile >= 0, "hawq_conv2d: in_planar input but no 3x3 band kernel takes this layer");
     }
     if (tile >= NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count() && tile < NUM_TILES + NUM_BAND_TILES + 2 + band_v2_count() + gemm_v2_count()) {

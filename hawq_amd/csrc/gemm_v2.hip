@@ -20,6 +20,11 @@
 //     RESIDUAL with a stored uint16 residual or with the identity conv's accumulators (quant_utils.py:415-456: two requants, the
 //     un-clamped sum, ReLU, uint16 out with the sticky overflow flag, the next QuantAct's int8).
 // int8 operands, fast-contract tables, K (and K2) multiples of 128, Cout a multiple of BN.
+// Round 6: (a) hawq4 operands (NIB; both operands 4-bit, Cin % 256 == 0: a 128-byte chunk is 256 channels, every 16-byte fragment feeds
+// two MFMA K-steps after the nibble unpack of band_v2.hip - weights as value * 16, accumulators shifted back by 4 once, exact) and hawq4
+// outputs, so that the reduce convs of the 4-bit schedules (bit_config.py:806, 1512) stream half the bytes instead of running the generic
+// register-staged kernel; (b) a RAW epilogue (int32 accumulators + bias, dense [M][Cout]) so that the parity tests pin these kernels'
+// accumulators directly (north_star: "bit-exact on the int32 pre-requant accumulators").
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -33,13 +38,15 @@ struct G2P {
     const char *x, *w;       // [N][H1][W1][K] int8 rows (NHWC) read at stride s1 ; hawq_pack_w1x1_k128 stream
     const char *x2, *w2;     // second phase: block input [N][H2][W2][K2] read at stride s2 ; packed identity weights
     const int32_t *ctab, *ctab_id;
-    char *out;               // int8: NHWC [M][Cout] or planes [Cout/16][M][16 B]; may be null (RESIDUAL)
+    const int32_t *bias;     // RAW only
+    int32_t *out_acc;        // RAW only: [M][Cout] int32
+    char *out;               // int8: NHWC [M][Cout] or planes [Cout/16][M][16 B]; hawq4: NHWC [M][Cout/2] or planes [Cout/32][M][16 B]; may be null (RESIDUAL)
     const char *res_in;      // [M][Cout] uint16 (single-branch RESIDUAL)
     char *res_out;           // [M][Cout] uint16 or null
     int *flags;
     int M, K, Cout, n1, n2;  // n1 / n2: 128-byte chunks of phase 1 / 2
     int Ho, Wo, H1, W1, s1, H2, W2, K2, s2;
-    int out_planar, q_lo, q_hi;
+    int out_planar, out_bits, q_lo, q_hi;
     int mq, eq, m_id, e_id;
     unsigned x_bytes, w_bytes, x2_bytes, w2_bytes;
     int dbg;
@@ -84,8 +91,21 @@ __device__ __forceinline__ void g2_lds_store_b32(unsigned addr, int v) { asm vol
 // byte offset of 16-byte slot s of row r inside a [rows][128 B] tile
 __device__ __forceinline__ unsigned g2_off(int r, int s) { return (unsigned)(r * 128 + ((s ^ ((r >> 1) & 7)) << 4)); }
 
-// EPI: HAWQ_EPI_REQUANT / HAWQ_EPI_RESIDUAL.  DUAL: the residual is the identity conv (second phase).  MODE: 0 tie-free, 2 exact ties.
-template <class C, int EPI, bool DUAL, int MODE>
+// hawq4 -> int8 operand dwords (see band_v2.hip b2_unpack16): two packed dwords = 16 channels = one MFMA K-step of this lane
+template <bool WEIGHT>
+__device__ __forceinline__ v4i g2_unpack16(unsigned x0, unsigned x1) {
+    v4i r;
+    if (WEIGHT) {
+        r.x = (int)((x0 << 4) & 0xF0F0F0F0u), r.y = (int)(x0 & 0xF0F0F0F0u), r.z = (int)((x1 << 4) & 0xF0F0F0F0u), r.w = (int)(x1 & 0xF0F0F0F0u);
+    } else {
+        r.x = (int)(x0 & 0x0F0F0F0Fu), r.y = (int)((x0 >> 4) & 0x0F0F0F0Fu), r.z = (int)(x1 & 0x0F0F0F0Fu), r.w = (int)((x1 >> 4) & 0x0F0F0F0Fu);
+    }
+    return r;
+}
+
+// EPI: HAWQ_EPI_REQUANT / HAWQ_EPI_RESIDUAL / HAWQ_EPI_RAW.  DUAL: the residual is the identity conv (second phase).  MODE: 0 tie-free,
+// 2 exact ties.  NIB: hawq4 operands (both phases).
+template <class C, int EPI, bool DUAL, int MODE, bool NIB = false>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm1x1_v2_kernel(const G2P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bool prof = HAWQ_DBG_BIT(p.dbg, 128) && p.dbgbuf;
@@ -215,9 +235,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm1x1_v2_kernel(const G2P p)
         _Pragma("unroll") for (int c = 0; c < C::CT; ++c) pin(wf[(KS) % C::NBUF][c]);                  \
         _Pragma("unroll") for (int q = 0; q < 2; ++q) pin(af[(KS) % C::NBUF][q]);                      \
         if (!HAWQ_DBG_BIT(p.dbg, 2)) {                                                                \
-            _Pragma("unroll") for (int q = 0; q < 2; ++q)                                             \
-                _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                     \
-                    ACC[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[(KS) % C::NBUF][c], af[(KS) % C::NBUF][q], ACC[c][q], 0, 0, 0); \
+            if constexpr (NIB) {                                                                      \
+                _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                    \
+                    v4i w8[C::CT], a8[2];                                                             \
+                    _Pragma("unroll") for (int c = 0; c < C::CT; ++c) w8[c] = g2_unpack16<true>((unsigned)wf[(KS) % C::NBUF][c][2 * hf], (unsigned)wf[(KS) % C::NBUF][c][2 * hf + 1]); \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) a8[q] = g2_unpack16<false>((unsigned)af[(KS) % C::NBUF][q][2 * hf], (unsigned)af[(KS) % C::NBUF][q][2 * hf + 1]); \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                     \
+                        _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                             \
+                            ACC[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w8[c], a8[q], ACC[c][q], 0, 0, 0); \
+                }                                                                                     \
+            } else {                                                                                  \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q)                                         \
+                    _Pragma("unroll") for (int c = 0; c < C::CT; ++c)                                 \
+                        ACC[c][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[(KS) % C::NBUF][c], af[(KS) % C::NBUF][q], ACC[c][q], 0, 0, 0); \
+            }                                                                                         \
         }                                                                                             \
     }
     const long long t_begin = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -277,7 +308,36 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm1x1_v2_kernel(const G2P p)
     __builtin_amdgcn_s_setprio(0);
     const long long t_loop_end = prof ? (long long)__builtin_readcyclecounter() : 0;
 
+    if constexpr (NIB) {   // the weights were value * 16: every sum is an exact multiple of 16
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[c][q][r] >>= 4;
+                    if (DUAL) acc2[c][q][r] >>= 4;
+                }
+    }
     // ---------------------------------------------------------------------- epilogue, straight from registers
+    if constexpr (EPI == HAWQ_EPI_RAW) {   // int32 accumulators + bias, dense [M][Cout]: a lane's 16 channels are 64 contiguous bytes
+#pragma unroll
+        for (int c = 0; c < C::CT; ++c) {
+            const int ch = c0 + wn * (32 * C::CT) + c * 32 + h * 16;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + wm * 64 + q * 32 + l31;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const v4i b4 = *reinterpret_cast<const v4i *>(p.bias + ch + 4 * gq);
+                    const v4i v = {acc[c][q][4 * gq] + b4.x, acc[c][q][4 * gq + 1] + b4.y, acc[c][q][4 * gq + 2] + b4.z, acc[c][q][4 * gq + 3] + b4.w};
+                    reinterpret_cast<v4i *>(p.out_acc + (size_t)m * p.Cout + ch)[gq] = v;
+                }
+            }
+        }
+        return;
+    }
     v4i rin[2][C::CT][2];
     if constexpr (EPI == HAWQ_EPI_RESIDUAL && !DUAL) {   // the stored residual: 32 contiguous bytes per (pixel, 16 channels), requested now
 #pragma unroll
@@ -355,10 +415,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm1x1_v2_kernel(const G2P p)
                     const v4i ra = {rp[0], rp[1], rp[2], rp[3]}, rb = {rp[4], rp[5], rp[6], rp[7]};
                     dst[0] = ra, dst[1] = rb;
                 }
-                if (p.out) {
+                if (p.out && p.out_bits == 8) {
                     const v4i ww = {w[0], w[1], w[2], w[3]};
                     char *dst = p.out_planar ? p.out + ((size_t)((c0 + lch) >> 4) * p.M + m) * 16 : p.out + (size_t)m * p.Cout + c0 + lch;
                     *reinterpret_cast<v4i *>(dst) = ww;
+                } else if (p.out) {   // hawq4: bytes hold values 0 .. 15, channels 4k .. 4k+3 in w[k]; low nibbles = channels 0-3 of an 8-group, high = 4-7
+                    const int ch = c0 + lch;
+                    const v2i ww = {w[0] | (w[1] << 4), w[2] | (w[3] << 4)};
+                    char *dst = p.out_planar ? p.out + ((size_t)(ch >> 5) * p.M + m) * 16 + ((ch >> 4) & 1) * 8 : p.out + (((size_t)m * p.Cout + ch) >> 1);
+                    *reinterpret_cast<v2i *>(dst) = ww;
                 }
             }
         }
@@ -378,10 +443,12 @@ using G128 = G2Cfg<2, 4, 2>;    // 128 px x 128 ch, 4-stage ring (132 KiB): wide
 constexpr int NUM_G2 = 3;
 
 typedef void (*G2Fn)(const G2P);
-struct G2Info { G2Fn fn[3][2]; int bn, lds, nt; };   // fn[REQUANT | RESIDUAL | RESIDUAL + identity conv][exact-tie]
-#define G2_ENTRY(CFG) {{{gemm1x1_v2_kernel<CFG, HAWQ_EPI_REQUANT, false, 0>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_REQUANT, false, 2>},    \
-                        {gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, false, 0>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, false, 2>},  \
-                        {gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, true, 0>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, true, 2>}}, CFG::BN, CFG::LDS_BYTES, CFG::NT}
+struct G2Info { G2Fn fn[2][3][2]; G2Fn raw[2]; int bn, lds, nt; };   // fn[hawq4][REQUANT | RESIDUAL | RESIDUAL + identity conv][exact-tie]; raw[hawq4]
+#define G2_FNS(CFG, N) {{gemm1x1_v2_kernel<CFG, HAWQ_EPI_REQUANT, false, 0, N>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_REQUANT, false, 2, N>},    \
+                        {gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, false, 0, N>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, false, 2, N>},  \
+                        {gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, true, 0, N>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_RESIDUAL, true, 2, N>}}
+#define G2_ENTRY(CFG) {{G2_FNS(CFG, false), G2_FNS(CFG, true)}, {gemm1x1_v2_kernel<CFG, HAWQ_EPI_RAW, false, 0, false>, gemm1x1_v2_kernel<CFG, HAWQ_EPI_RAW, false, 0, true>}, \
+                       CFG::BN, CFG::LDS_BYTES, CFG::NT}
 const G2Info kG2[NUM_G2] = {G2_ENTRY(G64D), G2_ENTRY(G64S), G2_ENTRY(G128)};
 
 }  // namespace
@@ -408,49 +475,60 @@ bool gemm_v2_applies(const hawq_conv_args *a, int v) {
     if (v < 0 || v >= NUM_G2) return false;
     const G2Info &gi = kG2[v];
     const bool dual = a->in2 != nullptr;
+    const bool nib = a->in_bits == 4 && a->w_bits == 4;
+    const int rowb = nib ? a->Cin >> 1 : a->Cin, rowb2 = nib ? a->Cin2 >> 1 : a->Cin2;   // bytes per pixel / weight row
     const long long Ho = (a->H - 1) / a->stride + 1, Wo = (a->W - 1) / a->stride + 1, M = (long long)a->N * Ho * Wo, Min = (long long)a->N * a->H * a->W;
-    const bool epi_ok = (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && a->out_bits == 8 && !dual) ||
+    const bool qout_ok = a->out_bits == 8 || (a->out_bits == 4 && a->q_lo >= 0 && a->q_hi <= 15 && a->Cout % 32 == 0);
+    const bool raw = a->epilogue == HAWQ_EPI_RAW;
+    const bool epi_ok = (raw && a->out_acc && a->bias && !dual) ||
+                        (a->epilogue == HAWQ_EPI_REQUANT && a->out_q && qout_ok && (a->out_bits == 8 || a->relu || a->q_lo >= 0) && !dual) ||
                         (a->epilogue == HAWQ_EPI_RESIDUAL && (dual || (a->res_in && a->res_in_bits == 16)) && (!a->res_out || (a->res_out_bits == 16 && a->flags)) &&
-                         !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || a->out_bits == 8));
-    const bool dual_ok = !dual || (a->wgt2_k128 && a->ctab_id && a->in2_bits == 8 && a->w2_bits == 8 && a->Cin2 % 128 == 0 &&
-                                   (long long)a->N * a->H2 * a->W2 * a->Cin2 < (1ll << 31) && (long long)a->Cout * a->Cin2 < (1ll << 31));
-    return a->KH == 1 && a->KW == 1 && a->stride >= 1 && a->pad == 0 && a->fast_tables != 0 && a->wgt_k128 != nullptr && a->ctab && !a->in_planar && epi_ok && dual_ok &&
-           a->in_bits == 8 && a->w_bits == 8 && a->Cin % 128 == 0 && a->Cout % gi.bn == 0 && (a->in_pitch == 0 || a->in_pitch == a->Cin) &&
-           (a->out_pitch == 0 || a->out_pitch == a->Cout) && Min * a->Cin < (1ll << 31) && (long long)a->Cout * a->Cin < (1ll << 31) && M * a->Cout < (1ll << 31);
+                         !a->res_no_relu && !a->res_clamp16 && (a->res_out || a->out_q) && (!a->out_q || qout_ok));
+    const bool dual_ok = !dual || (a->wgt2_k128 && a->ctab_id && a->in2_bits == a->in_bits && a->w2_bits == a->w_bits && rowb2 % 128 == 0 &&
+                                   (long long)a->N * a->H2 * a->W2 * rowb2 < (1ll << 31) && (long long)a->Cout * rowb2 < (1ll << 31));
+    return a->KH == 1 && a->KW == 1 && a->stride >= 1 && a->pad == 0 && (raw || (a->fast_tables != 0 && a->ctab)) && a->wgt_k128 != nullptr && !a->in_planar && epi_ok && dual_ok &&
+           ((a->in_bits == 8 && a->w_bits == 8) || nib) && rowb % 128 == 0 && a->Cout % gi.bn == 0 && (a->in_pitch == 0 || a->in_pitch == rowb) &&
+           (a->out_pitch == 0 || a->out_pitch == a->Cout) && Min * rowb < (1ll << 31) && (long long)a->Cout * rowb < (1ll << 31) && M * a->Cout < (1ll << 31);
 }
 
 int gemm_v2_launch(const hawq_conv_args *a, int v, int exact_tie, int dbg, void *stream) {
     const G2Info &gi = kG2[v];
     const bool dual = a->in2 != nullptr;
+    const bool nib = a->in_bits == 4;
+    const int rowb = nib ? a->Cin >> 1 : a->Cin, rowb2 = nib ? a->Cin2 >> 1 : a->Cin2;
     G2P p;
     p.x = (const char *)a->in, p.w = (const char *)a->wgt_k128, p.x2 = (const char *)a->in2, p.w2 = (const char *)a->wgt2_k128;
     p.ctab = a->ctab, p.ctab_id = a->ctab_id;
+    p.bias = a->bias, p.out_acc = a->out_acc;
     p.out = (char *)a->out_q, p.res_in = (const char *)a->res_in, p.res_out = (char *)a->res_out, p.flags = a->flags;
-    p.Ho = (a->H - 1) / a->stride + 1, p.Wo = (a->W - 1) / a->stride + 1, p.M = a->N * p.Ho * p.Wo, p.K = a->Cin, p.Cout = a->Cout;
+    p.Ho = (a->H - 1) / a->stride + 1, p.Wo = (a->W - 1) / a->stride + 1, p.M = a->N * p.Ho * p.Wo, p.K = rowb, p.Cout = a->Cout;
     p.H1 = a->H, p.W1 = a->W, p.s1 = a->stride;
-    p.n1 = a->Cin >> 7, p.n2 = dual ? a->Cin2 >> 7 : 0;
-    p.H2 = a->H2, p.W2 = a->W2, p.K2 = a->Cin2, p.s2 = a->stride2;
-    p.out_planar = a->out_planar;
+    p.n1 = rowb >> 7, p.n2 = dual ? rowb2 >> 7 : 0;
+    p.H2 = a->H2, p.W2 = a->W2, p.K2 = rowb2, p.s2 = a->stride2;
+    p.out_planar = a->out_planar, p.out_bits = a->out_bits;
     p.q_lo = a->relu && a->q_lo < 0 ? 0 : a->q_lo, p.q_hi = a->q_hi;
     p.mq = a->mq, p.eq = a->eq, p.m_id = a->m_id_scalar, p.e_id = a->e_id_scalar;
     if (a->epilogue != HAWQ_EPI_RESIDUAL || !a->out_q) p.mq = 0, p.eq = 33;
     if (a->epilogue != HAWQ_EPI_RESIDUAL || dual) p.m_id = 0, p.e_id = 33;
-    p.x_bytes = (unsigned)((long long)a->N * a->H * a->W * a->Cin), p.w_bytes = (unsigned)((long long)a->Cout * a->Cin);
-    p.x2_bytes = dual ? (unsigned)((long long)a->N * a->H2 * a->W2 * a->Cin2) : 0, p.w2_bytes = dual ? (unsigned)((long long)a->Cout * a->Cin2) : 0;
+    p.x_bytes = (unsigned)((long long)a->N * a->H * a->W * rowb), p.w_bytes = (unsigned)((long long)a->Cout * rowb);
+    p.x2_bytes = dual ? (unsigned)((long long)a->N * a->H2 * a->W2 * rowb2) : 0, p.w2_bytes = dual ? (unsigned)((long long)a->Cout * rowb2) : 0;
     p.dbg = dbg;
     static long long *dbg_dev = nullptr;
     if (HAWQ_DBG_BIT(dbg, 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 8 * sizeof(long long));
     p.dbgbuf = HAWQ_DBG_BIT(dbg, 128) ? dbg_dev : nullptr;
     static const bool attrs = [] {
         bool good = true;
-        for (const G2Info &i : kG2)
-            for (int k = 0; k < 6; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k >> 1][k & 1], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+        for (const G2Info &i : kG2) {
+            for (int k = 0; k < 12; ++k) good &= hipFuncSetAttribute((const void *)i.fn[k / 6][(k % 6) >> 1][k & 1], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+            for (int k = 0; k < 2; ++k) good &= hipFuncSetAttribute((const void *)i.raw[k], hipFuncAttributeMaxDynamicSharedMemorySize, i.lds) == hipSuccess;
+        }
         return good;
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv2d: hipFuncSetAttribute failed for the round-5 1x1 kernels");
     const int grid = ((p.M + 127) / 128) * (p.Cout / gi.bn);
     const int e = a->epilogue == HAWQ_EPI_REQUANT ? 0 : (dual ? 2 : 1);
-    hipLaunchKernelGGL(gi.fn[e][exact_tie ? 1 : 0], dim3(grid), dim3(gi.nt), gi.lds, (hipStream_t)stream, p);
+    G2Fn fn = a->epilogue == HAWQ_EPI_RAW ? gi.raw[nib ? 1 : 0] : gi.fn[nib ? 1 : 0][e][exact_tie ? 1 : 0];
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(gi.nt), gi.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {   // experiment hook (synchronises!)
         long long hb[5];

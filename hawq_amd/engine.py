@@ -103,6 +103,7 @@ class _Conv:
         # for 4-bit x 4-bit layers, int8 otherwise - a 4-bit weight in an int8 byte is the same integer
         self.w_bits = 4 if (mod.weight_bit <= 4 and in_bits == 4) else 8
         self.in_bits = in_bits
+        self.band_ok = self.k128_ok = False
         self.s_w = mod.convbn_scaling_factor.detach().float().cpu()
         self.w_host = w_int
         b = mod.bias_integer.detach().cpu().numpy().astype(np.float64)
@@ -110,16 +111,18 @@ class _Conv:
         if self.cin % 64 == 0 and self.cout % 64 == 0:
             wp = packing.pack_conv_weight(w_int, self.w_bits)
             self.w = torch.from_numpy(wp).to(dev)
-            # the round-5 3x3 kernels stream the same integers in tile order (include/hawq_mi355.h: hawq_conv_args.wgt_band)
-            self.w_band = None
+            # The round-5 kernels stream the same integers in their own tile order (include/hawq_mi355.h: hawq_conv_args.wgt_band /
+            # wgt_k128 / wgt2_k128).  Those copies are packed on first use (band() / k128()) and dropped again by
+            # IntegerEngine._release_unused_weights() for layers whose chosen tile is not such a kernel: a plan that never picks them
+            # does not hold the network's weights three times.
+            self._wp, self._dev = wp, dev
             rowb = self.cin * self.w_bits // 8   # bytes of a filter tap (hawq4: two channels per byte, Cin % 128 == 0 for the nibble kernels)
-            if ((self.kh, self.kw, self.stride, self.pad) == (3, 3, 1, 1) and rowb >= 128 and rowb % 64 == 0 and (self.w_bits == 8 or self.cin % 128 == 0)
-                    and not os.environ.get("HAWQ_NO_BAND2")):
-                self.w_band = torch.from_numpy(packing.pack_w3x3_band(wp, self.cout, rowb)).to(dev)
-            # ... and the round-5 streaming 1x1 kernels in 128-byte K chunks (hawq_conv_args.wgt_k128 / wgt2_k128)
-            self.w_k128 = None
-            if (self.kh, self.kw, self.pad) == (1, 1, 0) and self.w_bits == 8 and self.cin % 128 == 0 and not os.environ.get("HAWQ_NO_GEMM2"):
-                self.w_k128 = torch.from_numpy(packing.pack_w1x1_k128(wp, self.cout, self.cin)).to(dev)
+            self.band_ok = ((self.kh, self.kw, self.stride, self.pad) == (3, 3, 1, 1) and rowb >= 128 and rowb % 64 == 0
+                            and (self.w_bits == 8 or self.cin % 128 == 0) and not os.environ.get("HAWQ_NO_BAND2"))
+            # 128-byte K chunks: int8 rows of Cin % 128 == 0 channels, or (round 6) hawq4 rows of Cin % 256 == 0 channels
+            self.k128_ok = ((self.kh, self.kw, self.pad) == (1, 1, 0) and rowb % 128 == 0 and not os.environ.get("HAWQ_NO_GEMM2")
+                            and (self.w_bits == 8 or not os.environ.get("HAWQ_NO_GEMM2_NIB")))
+        self._w_band = self._w_k128 = None
         self.bias = _i32(self.b_host, dev)
         # exact per-channel bound on |accumulator| -> bit length, for the requant pre-shift check
         amax = max(abs(int(in_range[0])), abs(int(in_range[1]))) if in_range is not None else (128 if in_bits == 8 else 15)
@@ -128,6 +131,24 @@ class _Conv:
         if (self.vbits > 31).any():
             raise ValueError("int32 accumulator overflow is possible for this layer")
 
+    def band(self):
+        """hawq_pack_w3x3_band stream of this layer's weights on the device (None if no round-5 3x3 kernel could take it)."""
+        if self.band_ok and self._w_band is None:
+            self._w_band = torch.from_numpy(packing.pack_w3x3_band(self._wp, self.cout, self.cin * self.w_bits // 8)).to(self._dev)
+        return self._w_band
+
+    def k128(self):
+        """hawq_pack_w1x1_k128 stream (128-byte K chunks) of this layer's weights on the device, or None."""
+        if self.k128_ok and self._w_k128 is None:
+            self._w_k128 = torch.from_numpy(packing.pack_w1x1_k128(self._wp, self.cout, self.cin * self.w_bits // 8)).to(self._dev)
+        return self._w_k128
+
+    def release(self, band: bool, k128: bool):
+        if band:
+            self._w_band = None
+        if k128:
+            self._w_k128 = None
+
 
 class IntegerEngine:
     """Callable: fp32 NCHW images on the GPU -> fp32 logits, bit-identical to the reference's
@@ -135,6 +156,9 @@ class IntegerEngine:
     overflow flag (``overflowed()``); 32 stores int32.  ``from_buffers`` trusts the modules'
     integer buffers / scales as loaded from a quantized checkpoint (quant_train.py:665-670)
     instead of re-deriving them from the float parameters."""
+
+    # launches that recorded plans may still list as tuned although this build runs them on a kernel with nothing to tune
+    _UNTUNED_SINCE = ("quant_output",)
 
     def __init__(self, model, residual_bits: int = 16, from_buffers: bool = False, use_graph: bool = True,
                  keep_accumulators: bool = False, fast: bool = True, autotune: bool = True, chains: int = 0,
@@ -178,6 +202,9 @@ class IntegerEngine:
         # for ONE batch shape: that shape is built by replaying it - no timing at all -, any other shape is tuned as usual.  What
         # bench.py --plan and the multi-GPU path (rank 0 tunes, every rank replays: hawq_amd.dist.share_plan) hand over.
         self.plan = dict(plan) if plan else None
+        # storage policy of 4-bit expand-conv inputs (see _prepare_params): "0" nibbles, "1" int8 where the next block input is 8-bit,
+        # "2" int8 in every fusable unit.  A recorded plan carries the policy its launch list was built with.
+        self.expand_in8 = str(self.plan["expand_in8"]) if (self.plan and self.plan.get("expand_in8") not in (None, "")) else os.environ.get("HAWQ_EXPAND_IN8", "1")
         self.plan_source = "tuned in this process"
         self.subs = []
         self.stream = torch.cuda.Stream(device=self.dev)
@@ -248,13 +275,15 @@ class IntegerEngine:
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     store = self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")])
                     if (store == 4 and u.n_body == 3 and i + 1 == u.n_body and int(name.split('.')[0][len('stage'):]) in self.fuse_stages
-                            and nxt_u is not None and not nxt_u.resize_identity and block_input_bits(nxt_u) == 8
-                            and os.environ.get("HAWQ_EXPAND_IN8", "1") != "0"):
+                            and nxt_u is not None and not nxt_u.resize_identity
+                            and (self.expand_in8 == "2" or (self.expand_in8 == "1" and block_input_bits(nxt_u) == 8))):
                         # Mixed schedules (8-bit block inputs, 4-bit tensors inside the units): the 4-bit input of an expand conv
                         # whose successor's reduce conv runs the int8 pipeline anyway is stored as int8, so that the fused
                         # expand -> reduce launch takes the pair (it packs the reduce conv's 4-bit output itself).  Measured
-                        # (tools/nibble_pairs_ab.sh): bops_0.5 +1.6 %; pure W4A4 - whose block inputs are nibbles too - LOSES
-                        # 1.3 % with its pairs fused on int8 operands and keeps its nibble launches.
+                        # (tools/nibble_pairs_ab.sh): bops_0.5 +1.6 %; pure W4A4 - whose block inputs are nibbles too - LOST
+                        # 1.3 % in round 3 with its pairs fused on int8 operands and kept its nibble launches (policy "1", the default).
+                        # Policy "2" (round 6; recorded per plan as `expand_in8`): the same rule for nibble block inputs too - the W4A4
+                        # plan then fuses the same pairs as W8A8 while its 3x3 convs and un-fused reduce convs stream nibbles.
                         store = 8
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=store,
                                rng=_act_range(act.activation_bit, act.quant_mode),
@@ -362,8 +391,16 @@ class IntegerEngine:
                 return False
             q.epilogue, q.res_in, q.res_in_bits, q.res_out_bits = _lib.EPI_RESIDUAL, 1, 16, 16
         else:
-            q.epilogue, q.out_q = _lib.EPI_REQUANT, 1
-        return _lib.load().hawq_conv2d_band_tile(C.byref(q)) != 0
+            q.epilogue, q.out_q, q.out_bits, q.relu, q.q_lo, q.q_hi = _lib.EPI_REQUANT, 1, ent['out_bits'], 1, ent['rng'][0], ent['rng'][1]
+        if _lib.load().hawq_conv2d_band_tile(C.byref(q)) != 0:
+            return True
+        # a layer only the round-5 kernels take (planar input, host-packed weight stream): ADVICE r5
+        if in_bits != c.w_bits or c.band() is None:
+            return False
+        q.wgt_band, q.in_planar, q.ctab = c.band().data_ptr(), 1, 1
+        if is_last:
+            q.res_out_bits, q.flags, q.res_out = 16, 1, 1
+        return _lib.load().hawq_conv2d_band2_tile(C.byref(q)) != 0
 
     def _try_fuse(self, a, u, nxt, N, ho, wo, keep):
         """Expand conv launch `a` of unit `u` (RESIDUAL epilogue, already filled) + reduce conv of unit `nxt`:
@@ -386,8 +423,8 @@ class IntegerEngine:
             # the same integers from an int8 copy of its weights (the block input never takes a storage format at all)
             c.w8 = torch.from_numpy(packing.pack_conv_weight(c.w_host, 8)).to(self.dev)
         r.wgt, r.bias = (c.w if c.w_bits == 8 else c.w8).data_ptr(), c.bias.data_ptr()
-        if getattr(c, "w_k128", None) is not None:
-            r.wgt_k128 = c.w_k128.data_ptr()   # (for the two-launch form of the pair; ignored by the fused launch)
+        if c.w_bits == 8 and c.k128() is not None:
+            r.wgt_k128 = c.k128().data_ptr()   # (for the two-launch form of the pair; ignored by the fused launch)
         r.N, r.H, r.W, r.Cin, r.Cout, r.KH, r.KW, r.stride, r.pad = N, ho, wo, c.cin, c.cout, c.kh, c.kw, c.stride, c.pad
         r.in_bits, r.w_bits = 8, 8
         r.m, r.e, r.ctab = ent['m'].data_ptr(), ent['e'].data_ptr(), ent['ctab'].data_ptr()
@@ -409,8 +446,8 @@ class IntegerEngine:
         C.memmove(C.byref(r1), C.byref(r), C.sizeof(r1))
         r1.in_, r1.in_bits = q.data_ptr(), nxt['a_bits']
         r1.wgt, r1.w_bits = c.w.data_ptr(), c.w_bits
-        if c.w_bits != 8 or nxt['a_bits'] != 8:
-            r1.wgt_k128 = None
+        # the two-launch form reads the block input at its storage width: the 128-byte K chunks of the weights must be of that width too
+        r1.wgt_k128 = c.k128().data_ptr() if (c.k128() is not None and c.w_bits == nxt['a_bits']) else None
         pair = _FusedPair(er, a, r1, self.stream.cuda_stream)
         keep += [out, er, q, r1, pair]
         return pair, out, ob, planar
@@ -434,6 +471,46 @@ class IntegerEngine:
     def _build(self, N, H, W, x_view=None, logits_view=None):
         """Allocate activation buffers for batch N and record the launch list (choosing the chain count first
         when it was left open)."""
+        self._build_plan(N, H, W, x_view, logits_view)
+        if x_view is None and not os.environ.get("HAWQ_KEEP_PACKED"):
+            self._release_unused_weights()
+
+    def _release_unused_weights(self):
+        """Drop the round-5 weight streams (wgt_band / wgt_k128 / wgt2_k128: a second copy of a layer's weights in another order) of
+        every layer whose launches - in all chains of the plan just built - run a kernel that does not read them, and clear the
+        pointers in those launches' argument blocks (a later build of another batch shape packs them again on demand).
+        HAWQ_KEEP_PACKED=1 keeps them (tools/tile_sweep.py switches tiles after the build)."""
+        lib = _lib.load()
+        n, nb2, ng2 = lib.hawq_conv2d_num_tiles(), lib.hawq_conv2d_num_band2_tiles(), lib.hawq_conv2d_num_gemm2_tiles()
+        band_ids, gemm_ids = range(n - ng2 - nb2 + 1, n - ng2 + 1), range(n - ng2 + 1, n + 1)
+        args = []
+        for e in (self.subs or [self]):
+            args += list(getattr(e, "_conv_args", []))
+            for pr in getattr(e, "_er_args", []):
+                if not pr.fused:
+                    args += [pr.expand] + ([pr.reduce] if pr.reduce is not None else [])
+        live_band = {a.wgt_band for a in args if a.wgt_band and (a.tile in band_ids or a.tile == 0)}   # (tile 0: the library's own default may pick one)
+        live_k128 = {ptr for a in args if (a.tile in gemm_ids or a.tile == 0) for ptr in (a.wgt_k128, a.wgt2_k128) if ptr}
+        every = []
+        for e in (self.subs or [self]):
+            every += list(getattr(e, "_conv_args", []))
+            for pr in getattr(e, "_er_args", []):
+                every += [pr.expand, pr.er.expand, pr.er.reduce] + ([pr.reduce] if pr.reduce is not None else [])
+        for a in every:
+            if a.wgt_band and a.wgt_band not in live_band:
+                a.wgt_band = None
+            if a.wgt_k128 and a.wgt_k128 not in live_k128:
+                a.wgt_k128 = None
+            if a.wgt2_k128 and a.wgt2_k128 not in live_k128:
+                a.wgt2_k128 = None
+        convs = [c for u in self.P['units'] for c in [ent['conv'] for ent in u['convs']] + ([u['ident']] if u['resize'] else [])]
+        self.packed_weight_bytes = 0
+        for c in convs:
+            wb, wk = c._w_band, c._w_k128
+            c.release(wb is not None and wb.data_ptr() not in live_band, wk is not None and wk.data_ptr() not in live_k128)
+            self.packed_weight_bytes += sum(t.numel() for t in (c._w_band, c._w_k128) if t is not None)
+
+    def _build_plan(self, N, H, W, x_view=None, logits_view=None):
         if x_view is None:
             self._plan_on = bool(self.plan) and int(self.plan.get("batch", -1)) == N and not self.keep_acc
             if not self._plan_on and hasattr(self, "chains_req"):
@@ -446,7 +523,7 @@ class IntegerEngine:
                 self.chains = max(1, int(self.plan["chains"]))
                 self._build_chains(N, H, W, x_view, logits_view)
                 names = self.plan.get("conv_launches")
-                if names is not None and any(n not in names for n in self.tile_choice.keys()):
+                if names is not None and [n for n in names if n not in self._UNTUNED_SINCE] != list(self.tile_choice.keys()):
                     raise StalePlan("recorded for another launch list (other network, schedule or storage rule)")
                 self.plan_source = self.plan.get("source", "replayed a recorded plan")
                 return
@@ -470,7 +547,9 @@ class IntegerEngine:
             # layers, round 5 saw 1.51 ms for a topology whose plans replay at 1.40 ms) could discard the better topology for good: every
             # chain count within 5 % of the best gets the full set of trials, the fastest replay over all of them wins.
             best = min(timing.values())
-            order = sorted((c for c in timing if timing[c] <= 1.05 * best), key=timing.get) if N >= 8 else [min(timing, key=timing.get)]
+            # (at most the two fastest: each candidate costs HAWQ_TUNE_TRIALS full tuning passes - ~20 s each at batch 128 - and the
+            #  engines / graphs of discarded candidates are dropped as soon as their plan snapshot is taken)
+            order = sorted((c for c in timing if timing[c] <= 1.05 * best), key=timing.get)[:2] if N >= 8 else [min(timing, key=timing.get)]
             winner = None
             for c in order:
                 self.chains = c
@@ -533,7 +612,7 @@ class IntegerEngine:
         per = [strings(e) for e in self.subs]
         # the top-level strings are chain 0's; "per_chain" is only written when another chain runs something else
         extra = {"per_chain": per} if any(p != per[0] for p in per[1:]) else {}
-        return {"batch": int(self._batch[0]), "chains": int(self.chains), **extra,
+        return {"batch": int(self._batch[0]), "chains": int(self.chains), "expand_in8": self.expand_in8, **extra,
                 "tiles": ".".join(str(t) for t in self.tile_choice.values()),
                 "fused_variants": ".".join(str(t) for t in self.er_choice.values()),
                 "fused_split_tiles": ".".join(f"{a}.{b}" for a, b in getattr(self, "er_split_tiles", {}).values()),
@@ -695,10 +774,10 @@ class IntegerEngine:
                 ho, wo = (hin + 2 * c.pad - c.kh) // c.stride + 1, (win + 2 * c.pad - c.kw) // c.stride + 1
                 a = _lib.ConvArgs()
                 a.in_, a.wgt, a.bias = x_in.data_ptr(), c.w.data_ptr(), c.bias.data_ptr()
-                if getattr(c, "w_band", None) is not None and x_bits == c.w_bits:
-                    a.wgt_band = c.w_band.data_ptr()
-                if getattr(c, "w_k128", None) is not None and x_bits == 8:
-                    a.wgt_k128 = c.w_k128.data_ptr()
+                if x_bits == c.w_bits and c.band() is not None:
+                    a.wgt_band = c.band().data_ptr()
+                if x_bits == c.w_bits and c.k128() is not None:
+                    a.wgt_k128 = c.k128().data_ptr()
                 a.N, a.H, a.W, a.Cin, a.Cout = N, hin, win, c.cin, c.cout
                 a.KH, a.KW, a.stride, a.pad = c.kh, c.kw, c.stride, c.pad
                 a.in_bits, a.w_bits = x_bits, c.w_bits
@@ -739,8 +818,8 @@ class IntegerEngine:
                     if u['resize']:
                         ic = u['ident']
                         a.in2, a.wgt2, a.bias2 = qa.data_ptr(), ic.w.data_ptr(), ic.bias.data_ptr()
-                        if getattr(ic, "w_k128", None) is not None and u['a_bits'] == 8:
-                            a.wgt2_k128 = ic.w_k128.data_ptr()
+                        if u['a_bits'] == ic.w_bits and ic.k128() is not None:
+                            a.wgt2_k128 = ic.k128().data_ptr()
                         a.H2, a.W2, a.Cin2, a.stride2 = h, w, ic.cin, ic.stride
                         a.in2_bits, a.w2_bits = u['a_bits'], ic.w_bits
                         a.m_id, a.e_id = u['m_id'].data_ptr(), u['e_id'].data_ptr()
@@ -863,10 +942,12 @@ class IntegerEngine:
             ids = [int(v) for v in fixed.split(".")]
             names = (self.plan or {}).get("conv_launches") if getattr(self, "_plan_on", False) else None
             if names is not None and len(names) == len(ids) and list(names) != list(self._conv_names):
-                # a plan recorded with launches this build no longer tunes (the classifier since round 5): replay by NAME, ignore the extra ones
-                by_name = dict(zip(names, ids))
-                if any(n not in by_name for n in self._conv_names):
+                # a plan recorded with launches this build no longer tunes (_UNTUNED_SINCE: the classifier since round 5): replay by NAME.
+                # The ONLY relaxation: the recorded list minus those launches must be this build's list exactly - a superset recorded
+                # for a larger network (resnet101's plan on resnet50) is stale, not replayable
+                if [n for n in names if n not in self._UNTUNED_SINCE] != list(self._conv_names):
                     raise StalePlan("recorded for another launch list (other network, schedule or storage rule)")
+                by_name = dict(zip(names, ids))
                 ids = [by_name[n] for n in self._conv_names]
             if len(ids) != len(self._conv_args):
                 raise StalePlan(f"the recorded plan lists {len(ids)} tiles, this plan has {len(self._conv_args)} conv launches")

@@ -217,3 +217,30 @@ def test_band2_hawq4_operands_and_outputs(lib, orc, shape, mode):
                     lib.call("hawq_conv2d", C.byref(a), stream())
                     got = from_planar(out, (n, h, w, cout), out_bits) if outp else unpack_q(out, (n, h, w, cout), out_bits)
                     assert np.array_equal(got, ref), (bits, tile, out_bits, outp)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("bits", [8, 4])
+def test_band2_raw_accumulators(lib, orc, shape, bits):
+    """Round 6: north_star asks for bit-exactness "on the int32 pre-requant accumulators".  HAWQ_EPI_RAW instantiations of
+    the round-5 3x3 kernels expose exactly those (accumulators + bias, dense [M][Cout] int32) and are compared with the oracle's exact
+    sums (oracle.conv2d = quant_modules.py:489-494 restated in integers) - int8 and hawq4 operands, every geometry of this file."""
+    n, h, w, cin, cout = shape
+    if bits == 4 and cin % 128:
+        pytest.skip("hawq4 operands need Cin % 128 == 0")
+    rng = np.random.default_rng(31 * h + w + cin + bits)
+    x, wt, b = make_conv(rng, n, h, w, cin, cout, 3, bits, bits)
+    ref = orc.conv2d(x, wt, b, 1, 1)
+    ran = 0
+    for tile, (bm, band_px) in zip(_ids(lib), GEOM2):
+        a, keep = _args(lib, x, wt, b, tile, bits)
+        out = torch.full((ref.size,), -7, dtype=torch.int32, device='cuda')
+        a.epilogue, a.out_acc = lib.EPI_RAW, out.data_ptr()
+        if not _applies(bm, band_px, w, cin, bits):
+            assert lib.load().hawq_conv2d(C.byref(a), None) != 0   # refused, not mis-computed
+            continue
+        lib.call("hawq_conv2d", C.byref(a), stream())
+        got = out.cpu().numpy().reshape(n, h, w, cout).transpose(0, 3, 1, 2)
+        assert np.array_equal(got, ref), f"tile {tile}"
+        ran += 1
+    assert ran >= 1

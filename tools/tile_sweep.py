@@ -1,8 +1,10 @@
 """Whole-network tile sweep: for every conv launch of the fused plan and every tile id the library accepts for it,
 run the network with only that launch's tile changed and compare the logits with the all-default plan (bit-exact).
 usage (GPU box): python tools/tile_sweep.py [arch scheme batch ...]"""
+import os
 import sys
 import torch
+os.environ["HAWQ_KEEP_PACKED"] = "1"   # tiles are switched after the build: keep every layer's packed weight streams
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from hawq_amd import _lib
 from hawq_amd.api import build_quantized_resnet, calibrate
