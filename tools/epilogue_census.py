@@ -42,19 +42,27 @@ def main():
             continue
         end = next(j for j in range(i0, len(lines)) if "s_endpgm" in lines[j])
         print(f"== {dem[:160]}")
-        # loops: header label .. last instruction that branches back to it
+        # loops: LLVM annotates every basic block of a loop ("=>This Inner Loop Header: Depth=d" on the header, "in Loop: Header=BBx_y" on
+        # the others, on `.LBBx_y:` labels and on fall-through `; %bb.n:` markers alike) - a rotated loop's blocks need not be contiguous
+        blocks, cur = [], None   # (loop key or None, depth, [instruction lines])
+        for j in range(i0 + 1, end + 1):
+            ln = lines[j]
+            if re.match(r"^(\.LBB\S+:|; %bb\.\d+:)", ln):
+                mh = re.match(r"^\.LBB(\S+):.*Loop Header: Depth=(\d+)", ln)
+                mi = re.search(r"in Loop: Header=BB(\S+) Depth=(\d+)", ln)
+                key = (mh[1], int(mh[2])) if mh else ((mi[1], int(mi[2])) if mi else None)
+                cur = [key, []]
+                blocks.append(cur)
+            elif cur is not None:
+                cur[1].append(ln)
         headers = {}
-        for j in range(i0, end):
-            m = re.match(r"^(\.LBB\S+):.*Loop Header: Depth=(\d+)", lines[j])
-            if m:
-                headers[m[1]] = (j, int(m[2]))
-        for lab, (j0, depth) in headers.items():
-            back = max((j for j in range(j0, end) if re.search(r"s_c?branch\S*\s+" + re.escape(lab) + r"\b", lines[j])), default=None)
-            if back is None:
-                continue
+        for key, body in blocks:
+            if key is not None:
+                headers.setdefault(key, []).extend(body)
+        for (lab, depth), body in headers.items():
             cls, valu = collections.Counter(), collections.Counter()
-            for j in range(j0, back + 1):
-                ln = lines[j].strip()
+            for ln in body:
+                ln = ln.strip()
                 if not ln or ln.startswith((";", ".")) or ln.endswith(":"):
                     continue
                 op = ln.split()[0]
@@ -62,6 +70,7 @@ def main():
                 cls[c] += 1
                 if c == "VALU":
                     valu[re.sub(r"_e(32|64)$|_dpp$|_sdwa$", "", op)] += 1
+            lab = ".LBB" + lab
             tot = sum(cls.values())
             if cls["VALU"] + cls["MFMA"] < 8:
                 continue   # flag-polling / copy loops

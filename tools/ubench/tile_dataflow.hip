@@ -35,8 +35,13 @@ __device__ __forceinline__ int cperm(int i) { return (((i >> 2) & 1) << 4) + (i 
 // one 128 px x 64 ch tile: 4 waves, wave w owns pixels 32 w .. 32 w + 31 and all 64 channels (two 32 x 32 MFMA tiles); operands go straight
 // from global memory (L2-resident) into registers - the GEMM's own efficiency is not the question here, the launch structure around it is.
 // KREP repeats the K loop (same result: the accumulators are reset) to scale the tile's duration.
-template <int KREP>
+// COH: the activation rows are read and written with system-scope accesses (`buffer_load / buffer_store ... sc0 sc1`: served at the memory
+// side, no line left in this XCD's L2) - per-access coherence instead of whole-L2 write-backs / invalidations; the weights stay cached.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+template <int KREP, bool COH = false>
 __device__ __forceinline__ void tile(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int8_t *__restrict__ y, int M, int C, int m0, int c0) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, M * C, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)y, 0, M * C, 0x00020000);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
     int m = m0 + wave * 32 + l31;
     const bool live = m < M;
@@ -48,7 +53,9 @@ __device__ __forceinline__ void tile(const int8_t *__restrict__ x, const int8_t 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0;
         for (int k = 0; k < C; k += 32) {
-            const v4i b = *reinterpret_cast<const v4i *>(x + (size_t)m * C + k + h * 16);
+            v4i b;
+            if constexpr (COH) b = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rx, m * C + k + h * 16, 0, 17));
+            else b = *reinterpret_cast<const v4i *>(x + (size_t)m * C + k + h * 16);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const v4i a = *reinterpret_cast<const v4i *>(w + (size_t)(c0 + c * 32 + cperm(l31)) * C + k + h * 16);
@@ -71,7 +78,8 @@ __device__ __forceinline__ void tile(const int8_t *__restrict__ x, const int8_t 
             q[g] = (v[0] & 0xff) | ((v[1] & 0xff) << 8) | ((v[2] & 0xff) << 16) | ((v[3] & 0xff) << 24);
         }
         const v4i o = {q[0], q[1], q[2], q[3]};
-        *reinterpret_cast<v4i *>(y + (size_t)m * C + c0 + c * 32 + h * 16) = o;
+        if constexpr (COH) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o), ry, m * C + c0 + c * 32 + h * 16, 0, 17);
+        else *reinterpret_cast<v4i *>(y + (size_t)m * C + c0 + c * 32 + h * 16) = o;
     }
 }
 
@@ -92,30 +100,50 @@ struct Chain {
 };
 
 // ---- B: persistent, tile-level dataflow
-template <int KREP>
+// Control flow is kept WAVE-UNIFORM on purpose: every branch around a barrier is a scalar branch (readfirstlane'd values), the ticket is
+// drawn by all lanes of wave 0 together (lane 0 adds 1, the others 0) and every wave polls the flag word itself.  The first version drew the
+// ticket under `if (threadIdx.x == 0)`: the structurizer split the item loop around that lane-0 block and the waves of a workgroup then
+// executed different numbers of s_barrier - the kernel hung.
+template <int KREP, bool COH>
 __global__ __launch_bounds__(256) void dataflow_kernel(Chain p) {
     __shared__ int s_item;
     const int tiles_c = p.C >> 6, tiles_m = (p.M + 127) >> 7, per_layer = tiles_c * tiles_m, total = per_layer * p.L;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int *abort_flag = p.ticket + 2 * p.L;
     for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(p.ticket, 1);
+        if (wave == 0) {
+            const int old = __hip_atomic_fetch_add(p.ticket, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = __builtin_amdgcn_readfirstlane(old);
+        }
         __syncthreads();
-        const int item = s_item;
+        const int item = __builtin_amdgcn_readfirstlane(s_item);
         if (item >= total) return;
         const int l = item / per_layer, t = item % per_layer, tm = t / tiles_c, tc = t % tiles_c;
         if (l > 0) {
-            if (threadIdx.x == 0) {
-                const int *f = p.done + (size_t)(l - 1) * tiles_m + tm;
-                int spins = 0;   // (bounded: a protocol bug must end as a MISMATCH line, not as a hung GPU)
-                while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < tiles_c && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+            const int *f = p.done + (size_t)(l - 1) * tiles_m + tm;
+            int spins = 0;   // (bounded: a protocol bug must end as a MISMATCH line, not as a hung GPU)
+            // relaxed polls (an acquire load would invalidate this XCD's L2 on EVERY poll); ONE acquire fence behind the loop
+            while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < tiles_c) {
+                if (++spins > (1 << 12) || __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(abort_flag, 1 + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
             }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if constexpr (!COH) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this XCD's L2 forgets everything
         }
         const int8_t *x = l == 0 ? p.x0 : p.act[l & 1];
-        tile<KREP>(x, p.w + (size_t)l * p.C * p.C, p.act[(l + 1) & 1], p.M, p.C, tm * 128, tc << 6);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.done + (size_t)l * tiles_m + tm, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        tile<KREP, COH>(x, p.w + (size_t)l * p.C * p.C, p.act[(l + 1) & 1], p.M, p.C, tm * 128, tc << 6);
+        if constexpr (COH) {
+            // the sc0 sc1 stores are write-through: once vmcnt says they are done they are at the memory side; workgroup-scope ordering only
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (wave == 0) __hip_atomic_fetch_add(p.done + (size_t)l * tiles_m + tm, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // buffer_wbl2 sc1: this XCD's L2 writes back every dirty line
+            __syncthreads();   // every wave's stores are released; (also: s_item may be overwritten)
+            if (wave == 0) __hip_atomic_fetch_add(p.done + (size_t)l * tiles_m + tm, lane == 0 ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 // NOTE on B's buffers: layer l + 1 overwrites the buffer layer l read (ping-pong).  A tile of layer l + 1 for pixel tile tm may run while a
@@ -127,25 +155,33 @@ template <int KREP>
 __global__ __launch_bounds__(256) void gridbar_kernel(Chain p) {
     __shared__ int s_item;
     const int tiles_c = p.C >> 6, tiles_m = (p.M + 127) >> 7, per_layer = tiles_c * tiles_m;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int *abort_flag = p.ticket + 2 * p.L;
     for (int l = 0; l < p.L; ++l) {
         const int8_t *x = l == 0 ? p.x0 : p.act[l & 1];
         for (;;) {
-            if (threadIdx.x == 0) s_item = atomicAdd(p.ticket + l, 1);
+            if (wave == 0) {
+                const int old = __hip_atomic_fetch_add(p.ticket + l, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_item = __builtin_amdgcn_readfirstlane(old);
+            }
             __syncthreads();
-            const int t = s_item;
+            const int t = __builtin_amdgcn_readfirstlane(s_item);
             __syncthreads();
             if (t >= per_layer) break;
             tile<KREP>(x, p.w + (size_t)l * p.C * p.C, p.act[(l + 1) & 1], p.M, p.C, (t / tiles_c) * 128, (t % tiles_c) << 6);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int *arr = p.ticket + p.L + l;
-            __hip_atomic_fetch_add(arr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;   // (bounded: workgroups that are not co-resident would otherwise wait for ever)
-            while (__hip_atomic_load(arr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+        int *arr = p.ticket + p.L + l;
+        if (wave == 0) __hip_atomic_fetch_add(arr, lane == 0 ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;   // (bounded: workgroups that are not co-resident would otherwise wait for ever)
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (int)gridDim.x) {
+            if (++spins > (1 << 12) || __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(abort_flag, 1000000 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
         }
-        __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
@@ -174,7 +210,7 @@ static void run_shape(int M, int C, int L, int resident_per_cu) {
     Chain p;
     p.act[0] = act[0], p.act[1] = act[1], p.x0 = x0, p.w = w, p.ticket = ctr, p.done = ctr + 2 * L + 1, p.M = M, p.C = C, p.L = L;
     const int reps = 20;
-    float ms[3] = {0, 0, 0};
+    float ms[4] = {0, 0, 0, 0};
     auto mode_a = [&] {
         for (int l = 0; l < L; ++l)
             hipLaunchKernelGGL(layer_kernel<KREP>, dim3(per_layer), dim3(256), 0, st, l == 0 ? x0 : act[l & 1], w + (size_t)l * C * C, act[(l + 1) & 1], M, C);
@@ -192,21 +228,32 @@ static void run_shape(int M, int C, int L, int resident_per_cu) {
     CHECK(hipEventRecord(e1, st));
     CHECK(hipStreamSynchronize(st));
     CHECK(hipEventElapsedTime(&ms[0], e0, e1));
+    fprintf(stderr, "[M %d C %d res %d] A done\n", M, C, resident_per_cu);
     CHECK(hipMemcpy(ref, act[L & 1], hx.size(), hipMemcpyDeviceToDevice));
     std::vector<int8_t> href(hx.size()), hout(hx.size());
     CHECK(hipMemcpy(href.data(), ref, hx.size(), hipMemcpyDeviceToHost));
     const int grid = cus * resident_per_cu;
-    bool same[2] = {true, true};
-    for (int mode = 1; mode <= 2; ++mode) {
+    bool same[3] = {true, true, true};
+    const char *only = getenv("TD_MODES");   // e.g. "1" / "2" / "13"
+    for (int mode = 1; mode <= 3; ++mode) {
+        if (only && !strchr(only, '0' + mode)) continue;
         for (int r = -3; r < reps; ++r) {
             if (r == 0) CHECK(hipEventRecord(e0, st));
             CHECK(hipMemsetAsync(ctr, 0, nctr * sizeof(int), st));
-            if (mode == 1) hipLaunchKernelGGL(dataflow_kernel<KREP>, dim3(grid), dim3(256), 0, st, p);
-            else hipLaunchKernelGGL(gridbar_kernel<KREP>, dim3(grid), dim3(256), 0, st, p);
+            if (mode == 1) hipLaunchKernelGGL((dataflow_kernel<KREP, false>), dim3(grid), dim3(256), 0, st, p);
+            else if (mode == 2) hipLaunchKernelGGL(gridbar_kernel<KREP>, dim3(grid), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((dataflow_kernel<KREP, true>), dim3(grid), dim3(256), 0, st, p);
         }
         CHECK(hipEventRecord(e1, st));
         CHECK(hipStreamSynchronize(st));
         CHECK(hipEventElapsedTime(&ms[mode], e0, e1));
+        {
+            std::vector<int> hc(nctr);
+            CHECK(hipMemcpy(hc.data(), ctr, nctr * sizeof(int), hipMemcpyDeviceToHost));
+            long long dsum = 0;
+            for (size_t i = 2 * L + 1; i < nctr; ++i) dsum += hc[i];
+            fprintf(stderr, "  mode %d done: %.3f ms per chain; ticket[0] %d abort %d sum(done) %lld (expected %d)\n", mode, ms[mode] / reps, hc[0], hc[2 * L], dsum, mode != 2 ? per_layer * L : 0);
+        }
         CHECK(hipMemcpy(hout.data(), act[L & 1], hx.size(), hipMemcpyDeviceToHost));
         same[mode - 1] = memcmp(hout.data(), href.data(), hx.size()) == 0;
     }
@@ -217,22 +264,27 @@ static void run_shape(int M, int C, int L, int resident_per_cu) {
     CHECK(hipEventRecord(e1, st));
     CHECK(hipStreamSynchronize(st));
     CHECK(hipEventElapsedTime(&ms_set, e0, e1));
-    printf("M %6d C %4d L %2d krep %d  tiles/layer %4d  grid %4d | A launches %7.2f us/layer | B dataflow %7.2f us/layer (%s) | C grid barrier %7.2f us/layer (%s) | memset %5.2f us per chain\n",
-           M, C, L, KREP, per_layer, grid, ms[0] / reps / L * 1e3, (ms[1] - ms_set) / reps / L * 1e3, same[0] ? "same bytes" : "MISMATCH",
-           (ms[2] - ms_set) / reps / L * 1e3, same[1] ? "same bytes" : "MISMATCH", ms_set / reps * 1e3);
+    printf("M %6d C %4d L %2d  tiles/layer %4d  grid %4d | A launches %7.2f us/layer | B dataflow, L2 fences %7.2f (%s) | C grid barrier %7.2f (%s) | D dataflow, sc0 sc1 accesses %7.2f (%s) | memset %5.2f us per chain\n",
+           M, C, L, per_layer, grid, ms[0] / reps / L * 1e3, (ms[1] - ms_set) / reps / L * 1e3, same[0] ? "same bytes" : "MISMATCH",
+           (ms[2] - ms_set) / reps / L * 1e3, same[1] ? "same bytes" : "MISMATCH", (ms[3] - ms_set) / reps / L * 1e3, same[2] ? "same bytes" : "MISMATCH", ms_set / reps * 1e3);
     CHECK(hipGraphExecDestroy(ge)), CHECK(hipGraphDestroy(g));
     CHECK(hipFree(x0)), CHECK(hipFree(w)), CHECK(hipFree(act[0])), CHECK(hipFree(act[1])), CHECK(hipFree(ref)), CHECK(hipFree(ctr));
     CHECK(hipStreamDestroy(st));
 }
 
-int main() {
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    if (argc >= 5) {   // one shape: M C L workgroups-per-CU [krep]   (debugging / sweeps)
+        const int M = atoi(argv[1]), C = atoi(argv[2]), L = atoi(argv[3]), res = atoi(argv[4]), krep = argc > 5 ? atoi(argv[5]) : 1;
+        (void)krep;
+        run_shape<1>(M, C, L, res);
+        return 0;
+    }
     // stage-3-like (14 x 14 x 64 images, C = 256), stage-4-like (7 x 7 x 64 images, C = 512), and both at 128 images; 12 layers
     for (int res = 1; res <= 4; res *= 2) {
         run_shape<1>(12544, 256, 12, res);
         run_shape<1>(3136, 512, 12, res);
         run_shape<1>(25088, 256, 12, res);
-        run_shape<4>(12544, 256, 12, res);
-        run_shape<4>(3136, 512, 12, res);
     }
     return 0;
 }
