@@ -204,7 +204,8 @@ class IntegerEngine:
         self.plan = dict(plan) if plan else None
         # storage policy of 4-bit expand-conv inputs (see _prepare_params): "0" nibbles, "1" int8 where the next block input is 8-bit,
         # "2" int8 in every fusable unit.  A recorded plan carries the policy its launch list was built with.
-        self.expand_in8 = str(self.plan["expand_in8"]) if (self.plan and self.plan.get("expand_in8") not in (None, "")) else os.environ.get("HAWQ_EXPAND_IN8", "1")
+        # (a plan recorded before round 6 has no such key: it was recorded under policy "1")
+        self.expand_in8 = str(self.plan.get("expand_in8") or "1") if self.plan else os.environ.get("HAWQ_EXPAND_IN8", "2")
         self.plan_source = "tuned in this process"
         self.subs = []
         self.stream = torch.cuda.Stream(device=self.dev)
@@ -274,16 +275,19 @@ class IntegerEngine:
                     s_n = self._scale(act)
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     store = self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")])
-                    if (store == 4 and u.n_body == 3 and i + 1 == u.n_body and int(name.split('.')[0][len('stage'):]) in self.fuse_stages
-                            and nxt_u is not None and not nxt_u.resize_identity
-                            and (self.expand_in8 == "2" or (self.expand_in8 == "1" and block_input_bits(nxt_u) == 8))):
+                    fusable = (int(name.split('.')[0][len('stage'):]) in self.fuse_stages and nxt_u is not None and not nxt_u.resize_identity)
+                    if (store == 4 and u.n_body == 3 and i + 1 == u.n_body
+                            and (self.expand_in8 == "2" or (self.expand_in8 == "1" and fusable and block_input_bits(nxt_u) == 8))):
                         # Mixed schedules (8-bit block inputs, 4-bit tensors inside the units): the 4-bit input of an expand conv
                         # whose successor's reduce conv runs the int8 pipeline anyway is stored as int8, so that the fused
                         # expand -> reduce launch takes the pair (it packs the reduce conv's 4-bit output itself).  Measured
                         # (tools/nibble_pairs_ab.sh): bops_0.5 +1.6 %; pure W4A4 - whose block inputs are nibbles too - LOST
                         # 1.3 % in round 3 with its pairs fused on int8 operands and kept its nibble launches (policy "1", the default).
-                        # Policy "2" (round 6; recorded per plan as `expand_in8`): the same rule for nibble block inputs too - the W4A4
-                        # plan then fuses the same pairs as W8A8 while its 3x3 convs and un-fused reduce convs stream nibbles.
+                        # Policy "2" (round 6, the default; recorded per plan as `expand_in8`): EVERY bottleneck's 4-bit expand input is
+                        # stored as int8 - the expand(-> reduce) launches of a 4-bit schedule are then exactly the W8A8 plan's (same fused
+                        # pairs, same wave-private solo launches; they are bound by the residual epilogue, not by their K = 64..512 bytes)
+                        # while its 3x3 convs, un-fused reduce convs and identity convs stream nibbles (band_v2 / gemm_v2 NIB).  Same box,
+                        # fresh plans (profiles/r06_w4a4_ab.txt): W4A4 98.7-98.9 k (policy 1) -> 99.7 k img/s, W8A8 96.4-97.9 k.
                         store = 8
                     ent.update(m=_i32(mm, dev), e=_i32(ee, dev), out_bits=store,
                                rng=_act_range(act.activation_bit, act.quant_mode),
@@ -935,6 +939,10 @@ class IntegerEngine:
         n_tiles = _lib.load().hawq_conv2d_num_tiles()
         sp = self.stream.cuda_stream
         self._tile_times, self._er_times = {}, {}
+        # tile ids the tuner no longer tries: never chosen in any plan recorded in rounds 4-6 nor in this round's
+        # fresh tuning runs (profiles/r06_retired_tiles.md).  The kernels stay in the library under their ids - recorded plans, the
+        # parity tests and tools/tile_sweep.py still reach them - but a tuning pass no longer times them.  HAWQ_RETIRED_TILES="" re-enables.
+        retired = {int(v) for v in os.environ.get("HAWQ_RETIRED_TILES", "5,19").split(",") if v}
         # replay a recorded choice, no timing: the constructor's plan for this batch size, or HAWQ_TILES (dotted list as bench.py prints it).
         # A chain of a multi-chain engine replays the plan of the WHOLE batch it is a part of
         fixed = self._fixed("tiles")
@@ -987,7 +995,7 @@ class IntegerEngine:
                 times = {}
                 for rnd in range(2):  # two rounds, per-tile minimum: one hiccup must not decide a layer's tile
                     for tile in range(1, n_tiles + 1):
-                        if rnd and tile not in times:
+                        if (rnd and tile not in times) or tile in retired:
                             continue
                         a.tile = tile
                         try:
@@ -1011,7 +1019,7 @@ class IntegerEngine:
                 times = {}
                 for rnd in range(2):
                     for tile in range(1, n_tiles + 1):
-                        if rnd and tile not in times:
+                        if (rnd and tile not in times) or tile in retired:
                             continue
                         a.tile = tile
                         try:
