@@ -276,15 +276,17 @@ class IntegerEngine:
                     mm, ee = requant_table(s_x, c.s_w, s_n, vbits=c.vbits)
                     store = self._storage(self._store_bits(act), [getattr(u, f"quant_convbn{i + 1}")])
                     fusable = (int(name.split('.')[0][len('stage'):]) in self.fuse_stages and nxt_u is not None and not nxt_u.resize_identity)
+                    # (a resize unit's expand conv shares its launch with the identity conv, whose input - the block input - keeps its own
+                    #  storage: the dual launch wants equal operand widths in both branches, its exact-tie instantiations exist for nothing else)
                     if (store == 4 and u.n_body == 3 and i + 1 == u.n_body
-                            and (self.expand_in8 == "2" or (self.expand_in8 == "1" and fusable and block_input_bits(nxt_u) == 8))):
+                            and ((self.expand_in8 == "2" and not u.resize_identity) or (self.expand_in8 == "1" and fusable and block_input_bits(nxt_u) == 8))):
                         # Mixed schedules (8-bit block inputs, 4-bit tensors inside the units): the 4-bit input of an expand conv
                         # whose successor's reduce conv runs the int8 pipeline anyway is stored as int8, so that the fused
                         # expand -> reduce launch takes the pair (it packs the reduce conv's 4-bit output itself).  Measured
                         # (tools/nibble_pairs_ab.sh): bops_0.5 +1.6 %; pure W4A4 - whose block inputs are nibbles too - LOST
                         # 1.3 % in round 3 with its pairs fused on int8 operands and kept its nibble launches (policy "1", the default).
-                        # Policy "2" (round 6, the default; recorded per plan as `expand_in8`): EVERY bottleneck's 4-bit expand input is
-                        # stored as int8 - the expand(-> reduce) launches of a 4-bit schedule are then exactly the W8A8 plan's (same fused
+                        # Policy "2" (round 6, the default; recorded per plan as `expand_in8`): the 4-bit expand input of EVERY identity-pass-through
+                        # bottleneck is stored as int8 - the expand(-> reduce) launches of a 4-bit schedule are then exactly the W8A8 plan's (same fused
                         # pairs, same wave-private solo launches; they are bound by the residual epilogue, not by their K = 64..512 bytes)
                         # while its 3x3 convs, un-fused reduce convs and identity convs stream nibbles (band_v2 / gemm_v2 NIB).  Same box,
                         # fresh plans (profiles/r06_w4a4_ab.txt): W4A4 98.7-98.9 k (policy 1) -> 99.7 k img/s, W8A8 96.4-97.9 k.
