@@ -145,8 +145,9 @@ typedef struct hawq_conv_args {
        stream a workgroup consumes - [Cout/64][Cin/64][kh][kw][64 rows][64 B], the 16-byte slots of a row XOR-swizzled - so that every
        LDS-DMA instruction of the weight ring copies one contiguous KiB.  NULL = not provided: those tile ids refuse the layer. */
     const void *wgt_band;
-    /* ABI 5 - the round-5 1x1 kernels (gemm_v2.hip; 1x1 / pad 0 convs with Cin % 128 == 0, int8 operands, NHWC rows): the weights of
-       `wgt` / `wgt2` packed by hawq_pack_w1x1_k128 - [Cout/64][Cin/128][64 rows][128 B], 16-byte slot s of row r at s ^ ((r >> 1) & 7) -
+    /* ABI 5 - the round-5 1x1 kernels (gemm_v2.hip; 1x1 / pad 0 convs whose pixel row is a multiple of 128 BYTES - int8 operands with
+       Cin % 128 == 0 or, round 6, hawq4 operands (in_bits == w_bits == 4) with Cin % 256 == 0 -, NHWC rows): the weights of
+       `wgt` / `wgt2` packed by hawq_pack_w1x1_k128 - [Cout/64][row bytes/128][64 rows][128 B], 16-byte slot s of row r at s ^ ((r >> 1) & 7) -
        so that the K loop walks full 128-byte lines and every weight piece is a contiguous KiB.  NULL = not provided. */
     const void *wgt_k128;
     const void *wgt2_k128;
@@ -173,9 +174,15 @@ int hawq_conv2d_num_band2_tiles(void);
 int hawq_conv2d_band2_tile(const hawq_conv_args *args);
 int hawq_pack_w3x3_band(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin);
 /* ABI 5: the LAST hawq_conv2d_num_gemm2_tiles() tile ids are the round-5 streaming
- * 1x1 kernels (need args->wgt_k128 - and wgt2_k128 with a second branch -, NHWC int8 input, fast_tables; REQUANT, RESIDUAL on uint16
+ * 1x1 kernels (need args->wgt_k128 - and wgt2_k128 with a second branch -, NHWC input, fast_tables; REQUANT, RESIDUAL on uint16
  * residuals, or RESIDUAL with the identity conv as second branch).  hawq_conv2d_gemm2_first(): the 1-based id of the first of them.
- * hawq_pack_w1x1_k128: [Cout][Cin] int8 -> the stream described at hawq_conv_args.wgt_k128 (host pointers). */
+ * hawq_pack_w1x1_k128: [Cout][Cin] int8 -> the stream described at hawq_conv_args.wgt_k128 (host pointers; Cin = BYTES per weight row).
+ * Round 6 (no change of the argument block): both round-5 kernel families also take
+ *   - HAWQ_EPI_RAW (out_acc: int32 accumulators + bias, dense [M][Cout]; no tables needed) - what the parity tests compare with the
+ *     oracle's exact sums (quant_modules.py:489-494), and
+ *   - the streaming 1x1 kernels take hawq4 operands (both branches of a dual launch must have the same widths) and write int8 or
+ *     hawq4 outputs (out_bits 4: q_lo >= 0, q_hi <= 15), NHWC rows or channel-group planes - the reduce convs of the 4-bit schedules
+ *     (bit_config.py:806, 1512). */
 int hawq_conv2d_num_gemm2_tiles(void);
 int hawq_conv2d_gemm2_first(void);
 int hawq_pack_w1x1_k128(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Cin);
