@@ -21,6 +21,10 @@ shapes = [shapes[int(i)] for i in os.environ.get("SHAPES", "0,1,2,3").split(",")
 # SWEEP_CIN="128,256,512,1024": slope / intercept probe - the selected maps with Cout fixed and Cin (= the number of K steps, 3 per 64 channels) swept
 if os.environ.get("SWEEP_CIN"):
     shapes = [(h, int(c), cout) for (h, _, cout) in shapes for c in os.environ["SWEEP_CIN"].split(",")]
+# SWEEP_COUT="64,128,256": the selected maps with Cin fixed and the number of 64-channel output tiles (= workgroups per pixel tile) swept - what one
+# pixel tile's workgroups cost when 1, 2, 4 of them share the chip (profiles/r06_unit_fusion_analysis.md)
+if os.environ.get("SWEEP_COUT"):
+    shapes = [(h, cin, int(c)) for (h, cin, _) in shapes for c in os.environ["SWEEP_COUT"].split(",")]
 for n in batches:
     for (h, cin, cout) in shapes:
         M = n * h * h
