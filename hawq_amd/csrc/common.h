@@ -110,6 +110,23 @@ __device__ __forceinline__ int32_t dyadic_mode(int32_t v, const DyNt &c) {
     if (MODE == 2) return dyadic_tie(v, c);
     return dyadic_nt_k<MODE == 1>(v, c);
 }
+// Round 6 (profiles/r06_epilogue_census.md): the scalar identity table of a pass-through unit - the ratio of two residual scales, 0.25 <= r < 2 -
+// arrives lifted to (e = 33, k = 33 - e_orig >= 1).  The same rational is ((v << (k - 1)) * m) / 2^32: with the rounding constant 2^31 in the
+// addend the quotient IS the high word - no shift behind the v_mad_i64_i32 (one VALU instruction per residual output less).  Kernels
+// instantiated for it (`SC0`) are only launched when the host table has that form (ids0_form below); identical results by construction:
+// floor((v 2^(k-1) m + 2^31) / 2^32) == floor((v 2^k m + 2^32) / 2^33).
+__host__ __device__ __forceinline__ bool ids0_form(int ek) { return (ek & 0xff) == 33 && (ek >> 8) >= 1; }
+struct DyS0 {
+    int m, k;
+    long long add;   // 2^31
+};
+__device__ __forceinline__ DyS0 dys0_prepare(int m, int ek) {
+    DyS0 c;
+    c.m = m, c.k = (ek >> 8) - 1, c.add = 1ll << 31;
+    return c;
+}
+__device__ __forceinline__ int32_t dyadic_s0(int32_t v, const DyS0 &c) { return (int32_t)(((long long)(v << c.k) * (long long)c.m + c.add) >> 32); }
+
 // clamp(v, lo, hi) for lo <= hi in one instruction
 __device__ __forceinline__ int32_t med3i(int32_t v, int32_t lo, int32_t hi) {
     int32_t r;

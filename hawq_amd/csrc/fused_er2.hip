@@ -165,7 +165,9 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_pipelined_kernel
     const int wrow1 = wave_c * 32 + cperm(l31);                   // GEMM1: W3 slice row
     const int lch = wave_c * 32 + h * 16;                         // slice-local first channel of this lane's 16 outputs
     DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
-    asm volatile("" : "+v"(dids.add), "+v"(dq.add));              // opaque rounding constants in VGPR pairs: the scalar m already takes the constant bus of the v_mad_i64_i32, an SGPR addend would cost a v_mov_b64 per requant
+    constexpr bool SC0 = QK0 && !TIE;   // round 6: the QK0 instantiations also take the identity table in its shift-free form (launcher: ids0_form)
+    DyS0 dis0 = dys0_prepare(p.m_id_s, p.e_id_s);
+    asm volatile("" : "+v"(dids.add), "+v"(dq.add), "+v"(dis0.add));   // opaque rounding constants in VGPR pairs: the scalar m already takes the constant bus of the v_mad_i64_i32, an SGPR addend would cost a v_mov_b64 per requant
     const unsigned rowmask = (m0 + arow < p.M) ? 0xffffffffu : 0u;
     const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);
     const int res_row = (m0 + arow < p.M) ? m0 + arow : m0;       // rows beyond M read a valid row and are never stored
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_pipelined_kernel
             for (int k = 0; k < 4; ++k) {
                 const DyNt dm = e2_ctab_entry<K0>(ctb, lch + 4 * g + k);
                 const int a = dyadic_mode<MODE_C>(acc1[4 * g + k], dm);
-                const int b = dyadic_mode<MODE>(idin[k], dids);
+                const int b = SC0 ? dyadic_s0(idin[k], dis0) : dyadic_mode<MODE>(idin[k], dids);
                 o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
                 qv[k] = dyadic_mode<MODE_Q>(o[k], dq);                 // o >= 0, m >= 0: q >= 0; clamped from above in the pack
             }
@@ -455,7 +457,7 @@ int er2_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     }();
     HAWQ_REQUIRE(attrs, "hawq_conv_expand_reduce: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     const bool tie = ((e.fast_tables | r.fast_tables) & 4) != 0, ck0 = (e.fast_tables & 8) && (r.fast_tables & 8);
-    const bool qk0 = (e.eq >> 8) == 0;
+    const bool qk0 = (e.eq >> 8) == 0 && ids0_form(e.e_id_scalar);   // the QK0 instantiations: next-QuantAct table without pre-shift AND identity table in the shift-free form
     hipLaunchKernelGGL(ei.fn[tie ? 1 : (ck0 ? (qk0 ? 3 : 2) : (qk0 ? 4 : 0))], dim3((p.M + ei.bm - 1) / ei.bm), dim3(ei.nt), ei.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
     if (p.dbgbuf) {   // probe builds only (synchronises!)

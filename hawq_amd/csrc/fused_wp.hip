@@ -184,7 +184,9 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
             for (int r = 0; r < 16; ++r) acc2[c][r] = 0;
     }
     DyNt dids = dynt_prepare(p.m_id_s, p.e_id_s), dq = dynt_prepare(p.mq, p.eq);
-    asm volatile("" : "+s"(dids.add), "+s"(dq.add));   // opaque rounding constants: one v_mad_i64_i32 instead of v_mul_hi_i32 + v_add (see fused_er.hip)
+    constexpr bool SC0 = QK0 && !TIE;   // round 6: the QK0 instantiations also take the identity table in its shift-free form (launcher: ids0_form)
+    DyS0 dis0 = dys0_prepare(p.m_id_s, p.e_id_s);
+    asm volatile("" : "+s"(dids.add), "+s"(dq.add), "+s"(dis0.add));   // opaque rounding constants: one v_mad_i64_i32 instead of v_mul_hi_i32 + v_add (see fused_er.hip)
     const unsigned rowmask = valid ? 0xffffffffu : 0u;
     const int qhi2 = (p.q_hi & 0xffff) | (p.q_hi << 16);
     unsigned oor = 0;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
                     for (int k = 0; k < 4; ++k) {
                         const DyNt dm = wp_ctab<K0>(ctb, 32 * tl + 16 * h + 4 * g + k);
                         const int a = dyadic_mode<MODE_C>(acc1[tl][4 * g + k], dm);
-                        const int b = dyadic_mode<MODE_S>(idin[k], dids);
+                        const int b = SC0 ? dyadic_s0(idin[k], dis0) : dyadic_mode<MODE_S>(idin[k], dids);
                         o[k] = max(a + b, 0);                                  // no clamp: quant_utils.py:456
                         qv[k] = dyadic_mode<MODE_Q>(o[k], dq);                 // o >= 0, m >= 0: q >= 0; clamped from above in the pack
                     }
@@ -460,7 +462,7 @@ int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     const int ft = e.fast_tables | (wi.reduce ? r.fast_tables : 0);
     // bit 2: some table is not provably tie-free; bit 3 (on BOTH convs): every per-channel pre-shift is zero
     const bool tie = (ft & 4) != 0, ck0 = (e.fast_tables & 8) && (!wi.reduce || (r.fast_tables & 8));
-    const bool qk0 = (e.eq >> 8) == 0;
+    const bool qk0 = (e.eq >> 8) == 0 && ids0_form(e.e_id_scalar);   // the QK0 instantiations: next-QuantAct table without pre-shift AND identity table in the shift-free form
     HAWQ_REQUIRE(e.q_hi >= 0 && e.q_hi <= 32767, "hawq_conv_expand_reduce: q_hi outside [0, 32767]");
     hipLaunchKernelGGL(wi.fn[tie ? 2 : (ck0 ? (qk0 ? 3 : 1) : (qk0 ? 4 : 0))], dim3((p.M + wi.bm - 1) / wi.bm, wi.ysplit), dim3(wi.nt), wi.lds, (hipStream_t)stream, p);
     HAWQ_CHECK_HIP(hipGetLastError());
