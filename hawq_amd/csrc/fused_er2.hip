@@ -38,6 +38,7 @@ struct E2P {
     int y_planar, y_nib;
     int32_t *flags;
     long long *dbgbuf;   // probe builds (HAWQ_ABLATE, HAWQ_DBG=128): per-phase cycle sums of compute wave 0 and producer wave 0 of workgroup 8
+    int dbg;             // probe builds: HAWQ_DBG bits (256: phase-shift probe, see the slice loop)
 };
 
 __device__ __attribute__((aligned(16))) const int g_e2_zero16[4] = {0, 0, 0, 0};
@@ -289,9 +290,18 @@ __global__ __launch_bounds__(F::NT, F::MINB) void expand_reduce_pipelined_kernel
         E2_STAMP(1)
         store_slice(j - 1);
         E2_STAMP(2)
-        gemm1(j, acc1);
-        E2_STAMP(3)
-        epilogue1(j, acc1, rin, true);
+        if (HAWQ_DBG_BIT(p.dbg, 256) && wave_c == 1) {
+            // TIMING PROBE (probe build only, results wrong on purpose): the two compute waves of a SIMD are waves w and w + WM, i.e. the two
+            // channel halves.  Here the upper half runs its epilogue (on the accumulators of the PREVIOUS slice) BEFORE its GEMM1, so that on
+            // every SIMD one wave is in its MFMA phase while the other is in its VALU phase - what a phase-shifted schedule of this kernel
+            // could gain at best (profiles/r06_epilogue_census.md: the parts ADD because both waves pass the slice barrier together)
+            epilogue1(j, acc1, rin, true);
+            gemm1(j, acc1);
+        } else {
+            gemm1(j, acc1);
+            E2_STAMP(3)
+            epilogue1(j, acc1, rin, true);
+        }
         E2_STAMP(4)
     }
     // ---- iteration n: the last slice's stores and GEMM2
@@ -441,8 +451,10 @@ int er2_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     p.y_nib = r.out_bits == 4;
     p.flags = e.flags;
     p.dbgbuf = nullptr;
+    p.dbg = 0;
 #ifdef HAWQ_ABLATE
     static const int dbg_env = HAWQ_DBG_ENV();
+    p.dbg = dbg_env;
     static long long *dbg_dev = nullptr;
     if ((dbg_env & 128) && !dbg_dev) (void)hipMalloc(&dbg_dev, 16 * sizeof(long long));
     if (dbg_env & 128) p.dbgbuf = dbg_dev;
