@@ -486,6 +486,8 @@ def run_extras(args, dev, plans, model, eng):
     address space (round 6: one full bench run in ~10 died in glibc's heap check - "corrupted size vs. prev_size" - right after the RCCL
     self-check; the headline had been measured by then but its line was lost with the process)."""
     from hawq_amd import roofline
+    if os.environ.get("HAWQ_BENCH_FAIL_CHILD"):   # test hook: the child dies the way the sporadic abort did (the parent must still print its line)
+        os.abort()
     extra = {}
     n2 = max(10, args.steps // 2)
     # the same workload fed with uint8 NHWC images (SURVEY 8(f).2): table look-up input quantiser, 19 MB instead of
