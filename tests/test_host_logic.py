@@ -644,3 +644,30 @@ def test_profile_tools_on_a_synthetic_kernel_trace(tmp_path):
     assert abs(rec["share_of_forward_kernel_time"] - 20 / 35) < 1e-3 and rec["forward_kernels_in_trace"] == 3      # the tuning kernel is not counted
     ov = subprocess.run([sys.executable, os.path.join(root, "tools", "rocprof_overlap.py"), str(db), "2", "2"], capture_output=True, text=True, check=True).stdout
     assert "last 2 forwards (2 chains): 12 kernels" in ov and "| 2 |" in ov and "| 0 |" in ov
+
+
+def test_shift_free_identity_requant_equals_the_lifted_form_for_every_uint16():
+    """Round 6 (hawq_amd/csrc/common.h: ids0_form / dyadic_s0): a pass-through unit's identity table - the ratio of two residual scales in
+    [0.25, 2) - arrives lifted to (e = 33, k >= 1); the QK0 instantiations of the pair kernels apply it as hi32((v << (k - 1)) * m + 2^31)
+    without the shift behind the multiply.  Brute force over EVERY uint16 input: that form equals the lifted fast form
+    hi32((v << k) * m + 2^32) >> 1, and - where the host's proof excludes ties (the only case the fast kernels run without their tie
+    correction) - the reference's round-half-even (quant_utils.py:404-408 restated by the oracle)."""
+    import torch
+    from oracle import oracle
+    from hawq_amd.quant_utils import requant_table, tables_are_fast
+    v = np.arange(65536, dtype=np.int64)
+    seen_k = set()
+    for ratio in (0.2501, 0.26, 0.37, 0.4999, 0.5, 0.63, 0.8, 0.9999, 1.0, 1.3, 1.7, 1.9999):
+        m, ek = requant_table(torch.tensor([ratio * 0.7]), torch.ones(1), torch.tensor([0.7]), vbits=17)
+        m0, e0, k0 = int(m[0]), int(ek[0]) & 0xff, int(ek[0]) >> 8
+        assert e0 == 33 and k0 >= 1, (ratio, e0, k0)          # ids0_form
+        seen_k.add(k0)
+        lifted = (((v << k0) * m0 + (1 << 32)) >> 32) >> 1      # dyadic_nt: shift, v_mad_i64_i32, v_ashrrev_i32
+        s0 = ((v << (k0 - 1)) * m0 + (1 << 31)) >> 32           # dyadic_s0: shift, v_mad_i64_i32
+        assert np.array_equal(lifted, s0), ratio
+        if tables_are_fast(m, ek, 17):
+            assert np.array_equal(s0, oracle.dyadic(v.reshape(-1, 1), np.asarray([m0], np.int64), np.asarray([e0 - k0], np.int32)).reshape(-1)), ratio
+    assert seen_k == {1, 2, 3}
+    # a ratio below 0.25 needs no lift (k = 0): not the shift-free form - the launchers then pick the general instantiation
+    m, ek = requant_table(torch.tensor([0.2 * 0.7]), torch.ones(1), torch.tensor([0.7]), vbits=17)
+    assert (int(ek[0]) >> 8) == 0
