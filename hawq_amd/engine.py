@@ -202,8 +202,9 @@ class IntegerEngine:
         # for ONE batch shape: that shape is built by replaying it - no timing at all -, any other shape is tuned as usual.  What
         # bench.py --plan and the multi-GPU path (rank 0 tunes, every rank replays: hawq_amd.dist.share_plan) hand over.
         self.plan = dict(plan) if plan else None
-        # storage policy of 4-bit expand-conv inputs (see _prepare_params): "0" nibbles, "1" int8 where the next block input is 8-bit,
-        # "2" int8 in every fusable unit.  A recorded plan carries the policy its launch list was built with.
+        # storage policy of 4-bit expand-conv inputs (see _prepare_params): "0" nibbles, "1" int8 in a fusable unit whose successor's block
+        # input is 8-bit (rounds 3-5), "2" int8 in every identity-pass-through bottleneck (round 6, the default; env HAWQ_EXPAND_IN8).
+        # A recorded plan carries the policy its launch list was built with.
         # (a plan recorded before round 6 has no such key: it was recorded under policy "1")
         self.expand_in8 = str(self.plan.get("expand_in8") or "1") if self.plan else os.environ.get("HAWQ_EXPAND_IN8", "2")
         self.plan_source = "tuned in this process"
@@ -284,7 +285,7 @@ class IntegerEngine:
                         # whose successor's reduce conv runs the int8 pipeline anyway is stored as int8, so that the fused
                         # expand -> reduce launch takes the pair (it packs the reduce conv's 4-bit output itself).  Measured
                         # (tools/nibble_pairs_ab.sh): bops_0.5 +1.6 %; pure W4A4 - whose block inputs are nibbles too - LOST
-                        # 1.3 % in round 3 with its pairs fused on int8 operands and kept its nibble launches (policy "1", the default).
+                        # 1.3 % in round 3 with its pairs fused on int8 operands and kept its nibble launches (policy "1", the default of rounds 3-5).
                         # Policy "2" (round 6, the default; recorded per plan as `expand_in8`): the 4-bit expand input of EVERY identity-pass-through
                         # bottleneck is stored as int8 - the expand(-> reduce) launches of a 4-bit schedule are then exactly the W8A8 plan's (same fused
                         # pairs, same wave-private solo launches; they are bound by the residual epilogue, not by their K = 64..512 bytes)
