@@ -773,7 +773,7 @@ def main():
         extra = None
         for attempt in (1, 2):   # one retry: the failure seen was sporadic
             try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, timeout=1500,
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, timeout=900,
                                    env=dict(os.environ, HAWQ_PLAN_LABEL=(os.path.relpath(args.plan, ROOT) if not args.retune else "the plans this run tuned")))
                 line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
                 if r.returncode == 0 and line:
@@ -784,7 +784,10 @@ def main():
                         extra["extras_child_attempts"] = attempt
                     break
                 err = f"child exited with code {r.returncode}"
-            except Exception as exc:   # timeout, unparsable output
+            except subprocess.TimeoutExpired as exc:   # a hang is not retried: the bench must end in bounded time
+                extra = {"error": f"the secondary workloads did not complete (timeout after {exc.timeout:.0f} s); the headline above is unaffected"}
+                break
+            except Exception as exc:   # unparsable output
                 err = f"{type(exc).__name__}: {exc}"
             extra = {"error": f"the secondary workloads did not complete ({err}); the headline above is unaffected"}
         os.unlink(tmp.name)
