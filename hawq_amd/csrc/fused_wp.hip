@@ -37,7 +37,8 @@ struct WPP {
     const uint16_t *res_in;
     uint16_t *res_out;   // may be null (the next unit is a resize unit: it reads only q)
     uint8_t *y;          // REDUCE: the reduce conv's output [M][C] int8 (or channel-group planes)
-    uint8_t *q_out;      // !REDUCE: block input of the next unit [M][C3] int8, or null
+    uint8_t *q_out;      // !REDUCE: block input of the next unit [M][C3] int8 - or (q_nib, round 6) hawq4 [M][C3 / 2] -, or null
+    int q_nib;
     int M, C3;
     int m_id_s, e_id_s, mq, eq, q_hi;
     int y_lo, y_hi, y_planar, y_nib;   // y_nib: the reduce conv's output is stored hawq4 (two 4-bit channels per byte)
@@ -290,7 +291,18 @@ __global__ __launch_bounds__(F::NT, F::MINW) void expand_wp_kernel(const WPP p) 
             }
         }
         if constexpr (!F::REDUCE) {   // the next unit's block input [32 px][64 B] the same way (slots 2t + h, lds_off swizzle)
-            if (p.q_out) {
+            if (p.q_out && p.q_nib) {
+                // hawq4 block input (the next unit is a 4-bit layer whose input is stored as nibbles): a lane's 16 channels of tile tl are 8
+                // bytes - dword = (c0..c3 bytes) | (c4..c7 bytes) << 4, include/hawq_mi355.h - at byte 16 tl + 8 h of the pixel's 32-byte slice
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row reads above are done with the tile
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl)
+                    *reinterpret_cast<v2i *>(stg + l31 * 32 + 16 * tl + 8 * h) = v2i{qf[tl].x | (qf[tl].y << 4), qf[tl].z | (qf[tl].w << 4)};
+                const int r = lane >> 1, s2 = lane & 1;
+                const v4i v = *reinterpret_cast<const v4i *>(stg + lane * 16);   // (wave-private tile: LDS serves a wave's DS instructions in order)
+                if (pix0 + r < p.M)
+                    *reinterpret_cast<v4i *>((char *)p.q_out + (size_t)(pix0 + r) * (p.C3 >> 1) + j * 32 + s2 * 16) = v;
+            } else if (p.q_out) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row reads above are done with the tile
                 *reinterpret_cast<v4i *>(stg + lds_off(l31, h)) = qf[0];
                 *reinterpret_cast<v4i *>(stg + lds_off(l31, 2 + h)) = qf[1];
@@ -392,7 +404,7 @@ constexpr int NUM_WP = sizeof(kWP) / sizeof(kWP[0]);
 bool wp_expand_ok(const hawq_conv_args &e) {
     return (e.in_pitch == 0 || e.in_pitch == e.Cin) && (e.out_pitch == 0 || e.out_pitch == e.Cout) && e.KH == 1 && e.KW == 1 && e.stride == 1 && e.pad == 0 && e.in_bits == 8 && e.w_bits == 8 && e.fast_tables != 0 && !e.in2 &&
            !e.in_planar && e.epilogue == HAWQ_EPI_RESIDUAL && e.res_in && e.res_in_bits == 16 && (!e.res_out || e.res_out_bits == 16) &&
-           e.flags && e.ctab && e.Cout % 64 == 0 && e.out_bits == 8;
+           e.flags && e.ctab && e.Cout % 64 == 0 && (e.out_bits == 8 || (e.out_bits == 4 && e.q_lo >= 0 && e.q_hi <= 15));   // (4: the expand conv alone writing a hawq4 block input)
 }
 
 // index into kWP of the nth (1-based) variant that takes this launch, or -1
@@ -400,6 +412,7 @@ int wp_variant(const hawq_expand_reduce_args *a, int nth) {
     const hawq_conv_args &e = a->expand, &r = a->reduce;
     if (!wp_expand_ok(e)) return -1;
     const bool reduce = r.wgt != nullptr;
+    if (reduce && e.out_bits != 8) return -1;   // (a fused pair keeps the block input on chip: its storage width is moot, the caller says 8)
     if (reduce) {
         if (!(r.KH == 1 && r.KW == 1 && r.stride == 1 && r.pad == 0 && r.in_bits == 8 && r.w_bits == 8 && r.fast_tables != 0 && !r.in2)) return -1;
         if (r.epilogue != HAWQ_EPI_REQUANT || !r.ctab || !r.out_q || (r.out_bits != 8 && r.out_bits != 4) || !e.res_out) return -1;
@@ -435,6 +448,7 @@ int wp_launch(const hawq_expand_reduce_args *a, int nth, void *stream) {
     p.res_in = (const uint16_t *)e.res_in, p.res_out = (uint16_t *)e.res_out;
     p.y = wi.reduce ? (uint8_t *)r.out_q : nullptr;
     p.q_out = wi.reduce ? nullptr : (uint8_t *)e.out_q;
+    p.q_nib = !wi.reduce && e.out_bits == 4;
     const long long M = (long long)e.N * e.H * e.W;
     HAWQ_REQUIRE(M > 0 && M * e.Cout * 2 < (1ll << 32), "hawq_conv_expand_reduce: bad problem size");
     p.M = (int)M, p.C3 = e.Cout;

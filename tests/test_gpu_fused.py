@@ -169,6 +169,27 @@ def test_expand_alone_wave_private(lib, orc, shape, tie):
             assert np.array_equal(got, o if with_res else np.zeros_like(o)), (tile, with_res, k0)
             assert np.array_equal(unpack_q(qbuf, (n, h, w, c3), 8), keep['q_ref']), (tile, with_res, k0)
             assert keep['flags'].item() == 0
+    # round 6: the same launch writing a hawq4 block input (the next unit is a 4-bit layer): the oracle's q clamped to 15, nibble-packed
+    if not tie:
+        from hawq_amd.quant_utils import requant_table
+        mq4, eq4 = requant_table(torch.tensor([0.0005 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+        q4_ref = odyadic(orc, o, mq4, eq4, (0, 15))
+        assert 0 < float((q4_ref == 15).mean()) < 0.9
+        q4buf = torch.zeros(o.size // 2, dtype=torch.uint8, device='cuda')
+        mq0, eq0 = a.expand.mq, a.expand.eq
+        a.expand.out_q, a.expand.out_bits, a.expand.q_lo, a.expand.q_hi, a.expand.mq, a.expand.eq = q4buf.data_ptr(), 4, 0, 15, int(mq4[0]), int(eq4[0])
+        a.expand.fast_tables, a.expand.res_out = ft, keep['res_out'].data_ptr()
+        for tile in range(0, lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) + 1):
+            a.tile = tile
+            keep['res_out'].zero_(), q4buf.zero_()
+            lib.call("hawq_conv_expand_reduce", C.byref(a), stream())
+            got = keep['res_out'].cpu().numpy().astype(np.int64).reshape(n, h, w, c3).transpose(0, 3, 1, 2)
+            assert np.array_equal(got, o), (tile, "hawq4 block input")
+            assert np.array_equal(unpack_q(q4buf, (n, h, w, c3), 4), q4_ref), (tile, "hawq4 block input")
+        a.expand.q_hi = 16   # does not fit a nibble: refused
+        assert lib.load().hawq_conv_expand_reduce_variants(C.byref(a)) == 0
+        a.expand.out_q, a.expand.out_bits, a.expand.q_hi = qbuf.data_ptr(), 8, 127
+        a.expand.mq, a.expand.eq = mq0, eq0
     a.tile = nvar + 1
     assert lib.load().hawq_conv_expand_reduce(C.byref(a), None) != 0
 
