@@ -172,9 +172,10 @@ def test_expand_alone_wave_private(lib, orc, shape, tie):
     # round 6: the same launch writing a hawq4 block input (the next unit is a 4-bit layer): the oracle's q clamped to 15, nibble-packed
     if not tie:
         from hawq_amd.quant_utils import requant_table
-        mq4, eq4 = requant_table(torch.tensor([0.0005 * 0.7]), torch.ones(1), torch.tensor([0.7]))
+        r4 = 15.0 / max(1.0, float(np.percentile(o, 70)))   # ~30 % of the outputs reach the 4-bit clamp
+        mq4, eq4 = requant_table(torch.tensor([r4 * 0.7], dtype=torch.float32), torch.ones(1), torch.tensor([0.7]))
         q4_ref = odyadic(orc, o, mq4, eq4, (0, 15))
-        assert 0 < float((q4_ref == 15).mean()) < 0.9
+        assert 0.05 < float((q4_ref == 15).mean()) < 0.9
         q4buf = torch.zeros(o.size // 2, dtype=torch.uint8, device='cuda')
         mq0, eq0 = a.expand.mq, a.expand.eq
         a.expand.out_q, a.expand.out_bits, a.expand.q_lo, a.expand.q_hi, a.expand.mq, a.expand.eq = q4buf.data_ptr(), 4, 0, 15, int(mq4[0]), int(eq4[0])

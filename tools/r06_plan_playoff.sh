@@ -7,6 +7,7 @@ n=${1:-3}
 O=gpurun_out
 W="--arch ${ARCH:-resnet50} --scheme ${SCHEME:-uniform8}"   # ARCH= / SCHEME= : any workload of profiles/plans.json
 T=${TAG:-r6}
+# TUNE_ENV="HAWQ_CHAINS=3": environment of the tuning runs only (the replays take everything from the plan files)
 export HAWQ_TUNE_TRIALS=${HAWQ_TUNE_TRIALS:-6}
 pr() { python -c "
 import json, sys
@@ -14,7 +15,7 @@ d = json.loads(sys.stdin.readline())
 print('$1', d['value'], 'img/s', d['ms_per_step'], 'ms | gpu', d['timing']['mean_ms'], '+-', d['timing']['std_ms'], '| trials', d['config'].get('plan_trials_ms'), '| tiles', d['config']['autotuned_tiles'].replace('.', ' '), '| variants', d['config']['fused_variants'].replace('.', ' '))"; }
 {
 for i in $(seq $n); do
-  python bench.py $W --retune --no-cpu-baseline --no-extra --save-plan $O/${T}_plans_p$i.json 2>/dev/null | pr "tuning run p$i:"
+  env $TUNE_ENV python bench.py $W --retune --no-cpu-baseline --no-extra --save-plan $O/${T}_plans_p$i.json 2>/dev/null | pr "tuning run p$i:"
 done
 for rnd in 1 2 3; do
   python bench.py $W --no-extra --no-cpu-baseline --steps 60 --warmup 10 2>/dev/null | pr "round $rnd recorded:"
