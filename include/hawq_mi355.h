@@ -201,7 +201,9 @@ int hawq_pack_w1x1_k128(const int8_t *src, int8_t *dst, int32_t Cout, int32_t Ci
  * fused_er.hip first, then the wave-private ones of fused_wp.hip: same results, different organisation of the launch).
  * reduce.wgt == NULL (round 3): the expand conv ALONE on the wave-private kernel - `expand` exactly as for hawq_conv2d with the
  * RESIDUAL epilogue (single branch, uint16 residual in, 8-bit out_q, res_out optional; expand.Cin in {64, 128, 256, 512}); some
- * variants split the output channels over gridDim.y.  0 variants = use hawq_conv2d. */
+ * variants split the output channels over gridDim.y.  Round 6: expand.out_bits 4 (0 <= q_lo, q_hi <= 15) writes the next unit's block
+ * input as hawq4 rows of Cout / 2 bytes - the last expand conv of a stage in a 4-bit schedule, whose successor reads nibbles
+ * (bit_config.py:806, 1512).  0 variants = use hawq_conv2d. */
 typedef struct hawq_expand_reduce_args {
     hawq_conv_args expand;
     hawq_conv_args reduce;
